@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py - images/sec of descriptor extraction (ResNet101-GeM, 1024x1024) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (dir_forward: prep -> trunk -> GeM -> FC -> L2) over one batch
+of synthetic normalised images that is already resident in HBM.  Database images are sharded
+image-parallel over the ranks (no data-path collective inside a step); after the K steps each rank
+all-gathers its shard's descriptor block once over RCCL/xGMI (the one exchange step the path has,
+inside the timed region for N > 1).  Weights are the deterministic synthetic checkpoint of
+oracle/dir_oracle.py (there is no network for real ones).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel family (implicit-GEMM conv), algorithmic FLOPs / event-timed
+                launch durations collected inside this process over the timed steps
+  cpu_baseline  the CPU oracle (a port of the reference forward) timed on this box's host cores
+                on a bounded sample of the same workload (rank 0, N == 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0}   # dense MFMA, MI355X_MICROARCH.md (no sparsity)
+GFLOP_PER_IMG = {('resnet101', 1024): 325.99, ('resnet50', 224): 8.183}
+
+
+def cpu_baseline(arch, size, budget_s):
+    """CPU oracle forward, batch 1 (the reference's default path, test_dir.py:52-55), all cores."""
+    import dir_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.synth_state_dict(arch, seed=7)
+    x = O.synth_images(11, 1, size, size)
+    O.rmac_forward(sd, arch, x)   # warm-up (allocator, oneDNN primitive cache)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.rmac_forward(sd, arch, x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {'value': round(n / el, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '%d x %s fp32 %dx%d forward, batch 1, oracle/dir_oracle.py (%.1f s)' % (n, arch, size, size, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
+    ap.add_argument('--arch', default='resnet101')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'])
+    ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
+    ap.add_argument('--layers', action='store_true', help='also print the per-layer profile to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
+
+    import dir_oracle as O
+    from dirtorch_amd import nets
+    net = nets.create_model(args.arch + '_rmac', pretrained='')
+    net.load_state_dict(O.synth_state_dict(args.arch, seed=7))
+    net.compute_dtype = args.dtype
+    net.cuda().eval()
+
+    B, S, K, Wm = args.batch, args.size, args.steps, args.warmup
+    g = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    x = torch.randn(B, 3, S, S, generator=g, device='cuda')       # normalised-image statistics
+    D = net.out_dim
+    shard = torch.empty(K * B, D, device='cuda')                  # this rank's descriptor block
+
+    net.autotune = not args.no_autotune
+    net(x)                                                        # build engine, (autotune), first touch
+    net.autotune = False
+    for _ in range(Wm):
+        net(x)
+    torch.cuda.synchronize()
+
+    net.set_profiling(256 * (K + 1))    # event pairs pre-created: nothing is allocated while timing
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        shard[k * B:(k + 1) * B] = net(x)
+    if dist is not None:
+        allb = torch.empty(world * K * B, D, device='cuda')
+        dist.all_gather_into_tensor(allb, shard)                  # one exchange step (RCCL)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    prof = net.get_profile()
+    net.set_profiling(False)
+
+    if rank == 0:
+        fam = {}
+        for r in prof:
+            f = fam.setdefault(r['kernel'], [0.0, 0.0, 0.0, 0])
+            f[0] += r['ms']
+            f[1] += r['flops']
+            f[2] += r['bytes']
+            f[3] += 1
+        conv_ms = sum(v[0] for k, v in fam.items() if k.startswith('conv_igemm'))
+        conv_fl = sum(v[1] for k, v in fam.items() if k.startswith('conv_igemm'))
+        dom = max((k for k in fam if k.startswith('conv_igemm')), key=lambda k: fam[k][0])
+        dms, dfl, dby, dn = fam[dom]
+        achieved = dfl / (dms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # PMC-derived HBM bytes / launch, if collected
+        if os.path.isfile(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+                'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
+                'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
+                'all_conv_tflops': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                'all_conv_ms_per_step': round(conv_ms / K, 4),
+                'all_kernels_ms_per_step': round(sum(v[0] for v in fam.values()) / K, 4)}
+        if args.layers:
+            agg = {}
+            for r in prof:
+                a = agg.setdefault((r['name'], r['kernel']), [0.0, r['flops'], r['bytes'], 0])
+                a[0] += r['ms']
+                a[3] += 1
+            for (name, kern), (ms, fl, by, n) in agg.items():
+                ms /= n
+                print('%-24s %-36s %8.3f ms %8.1f TF/s %8.1f GB/s' % (
+                    name, kern, ms, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(args.arch, S, args.cpu_seconds)
+        value = world * B * K / el
+        out = {
+            'metric': 'images/sec descriptor extraction (%s-GeM, %dx%d)' % (args.arch, S, S),
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+            'ms_per_step': round(el / K * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: %s_rmac (AP-GeM head) single-scale %dx%d descriptor extraction, '
+                                   '1 process per GPU, synthetic weights + images' % (args.arch, S, S),
+                       'batch_per_gpu': B, 'global_batch': world * B, 'input': 'fp32 NCHW resident in HBM',
+                       'gflop_per_image': GFLOP_PER_IMG.get((args.arch, S)),
+                       'tflops_per_gpu': round(value / world * GFLOP_PER_IMG.get((args.arch, S), 0) / 1e3, 1),
+                       'parallelism': 'image-parallel shards, 1 all-gather of descriptors' if world > 1 else 'single GPU'},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,291 @@
+// c_api.hip — the extern "C" surface declared in include/dir_engine.h.
+// Nothing above this file knows about Python or torch; nothing below it throws.
+#include <new>
+
+#include "engine.h"
+
+namespace dir {
+const char* last_error();
+}
+using namespace dir;
+
+#define DIR_TRY try {
+#define DIR_CATCH                                                   \
+    }                                                               \
+    catch (const std::bad_alloc&) {                                 \
+        return fail(DIR_ERR_NOMEM, "out of host memory");           \
+    }                                                               \
+    catch (const std::exception& ex) {                              \
+        return fail(DIR_ERR_INVALID, std::string("exception: ") + ex.what()); \
+    }                                                               \
+    catch (...) {                                                   \
+        return fail(DIR_ERR_INVALID, "unknown exception");          \
+    }
+
+extern "C" {
+
+const char* dir_last_error(void) { return last_error(); }
+const char* dir_version(void) { return "dir_engine 0.1 gfx950"; }
+
+int dir_engine_create(const dir_model_desc* desc, int device, dir_engine** out) {
+    DIR_TRY
+    if (!desc || !out) return fail(DIR_ERR_INVALID, "create: null argument");
+    if (desc->pooling < DIR_POOL_GEM || desc->pooling > DIR_POOL_AVG)
+        return fail(DIR_ERR_INVALID, "create: bad pooling mode");  // ValueError(pooling), rmac_resnet.py:31
+    if (!desc->without_fc && desc->out_dim <= 0) return fail(DIR_ERR_INVALID, "create: out_dim <= 0");
+    int ndev = 0;
+    DIR_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(DIR_ERR_INVALID, "create: no such device");
+    dir_engine* e = new dir_engine();
+    e->desc = *desc;
+    e->device = device;
+    int rc = e->build_graph();
+    if (rc != DIR_OK) {
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_engine_destroy(dir_engine* e) {
+    DIR_TRY
+    if (!e) return DIR_OK;
+    e->release();
+    for (ProfSlot& s : e->prof) {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    delete e;
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_engine_set_tensor(dir_engine* e, const char* key, const float* data, const int64_t* shape,
+                          int ndim) {
+    DIR_TRY
+    if (!e || !key || !data || ndim < 0 || (ndim > 0 && !shape))
+        return fail(DIR_ERR_INVALID, "set_tensor: null argument");
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);  // DataParallel prefix, common.py:128-131
+    if (k.size() >= 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) return DIR_OK;
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(DIR_ERR_INVALID, "set_tensor: negative dimension");
+        t.shape.push_back(shape[i]);
+        n *= shape[i];
+    }
+    t.data.assign(data, data + n);
+    e->state[k] = std::move(t);
+    e->finalized = false;
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_engine_finalize(dir_engine* e, int dtype) {
+    DIR_TRY
+    if (!e) return fail(DIR_ERR_INVALID, "finalize: null engine");
+    return e->finalize(dtype);
+    DIR_CATCH
+}
+
+int dir_engine_out_dim(const dir_engine* e, int* out_dim) {
+    if (!e || !out_dim) return fail(DIR_ERR_INVALID, "out_dim: null argument");
+    *out_dim = e->desc.without_fc ? e->feat_dim : e->desc.out_dim;
+    return DIR_OK;
+}
+
+int dir_workspace_bytes(const dir_engine* e, int B, int H, int W, size_t* bytes) {
+    DIR_TRY
+    if (!e || !bytes) return fail(DIR_ERR_INVALID, "workspace_bytes: null argument");
+    Plan p;
+    int rc = e->plan(B, H, W, &p);
+    if (rc != DIR_OK) return rc;
+    *bytes = p.total;
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_forward(dir_engine* e, const void* img, int B, int H, int W, int fmt, float* desc_out,
+                void* ws, size_t ws_bytes, void* stream) {
+    DIR_TRY
+    if (!e || !img || !desc_out) return fail(DIR_ERR_INVALID, "forward: null argument");
+    return e->forward(img, B, H, W, fmt, desc_out, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes,
+                      (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, int fmt,
+                         void* feat_out, int* h, int* w, int* c, void* ws, size_t ws_bytes,
+                         void* stream) {
+    DIR_TRY
+    if (!e || !img || !feat_out) return fail(DIR_ERR_INVALID, "forward_features: null argument");
+    return e->forward(img, B, H, W, fmt, nullptr, feat_out, h, w, c, ws, ws_bytes,
+                      (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_engine_autotune(dir_engine* e, int B, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    DIR_TRY
+    if (!e) return fail(DIR_ERR_INVALID, "autotune: null engine");
+    const bool was_prof = e->profiling;
+    e->profiling = false;
+    e->tuning = true;
+    int rc = e->forward(nullptr, B, H, W, DIR_IMG_F32_NCHW, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, ws, ws_bytes, (hipStream_t)stream);
+    e->tuning = false;
+    e->profiling = was_prof;
+    if (rc != DIR_OK) return rc;
+    DIR_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_engine_set_profiling(dir_engine* e, int enabled) {
+    if (!e) return fail(DIR_ERR_INVALID, "set_profiling: null engine");
+    e->profiling = enabled != 0;
+    e->prof_used = 0;
+    // enabled > 1: pre-create that many event pairs so none is created inside a timed region
+    while ((int)e->prof.size() < enabled && enabled > 1) {
+        ProfSlot s;
+        DIR_HIP_CHECK(hipEventCreate(&s.start));
+        DIR_HIP_CHECK(hipEventCreate(&s.stop));
+        e->prof.push_back(s);
+    }
+    return DIR_OK;
+}
+
+int dir_engine_get_profile(dir_engine* e, dir_prof_record* out, int cap, int* n) {
+    DIR_TRY
+    if (!e || !n) return fail(DIR_ERR_INVALID, "get_profile: null argument");
+    const int have = (int)e->prof_used;
+    for (int i = 0; i < have; ++i) {
+        ProfSlot& s = e->prof[i];
+        DIR_HIP_CHECK(hipEventSynchronize(s.stop));
+        if (out && i < cap) {
+            float ms = 0.f;
+            DIR_HIP_CHECK(hipEventElapsedTime(&ms, s.start, s.stop));
+            dir_prof_record& r = out[i];
+            memset(&r, 0, sizeof(r));
+            strncpy(r.name, s.name.c_str(), sizeof(r.name) - 1);
+            strncpy(r.kernel, s.kernel.c_str(), sizeof(r.kernel) - 1);
+            r.flops = s.flops;
+            r.bytes = s.bytes;
+            r.ms = ms;
+        }
+    }
+    *n = have;
+    e->prof_used = 0;
+    return DIR_OK;
+    DIR_CATCH
+}
+
+// ---- per-op entry points --------------------------------------------------------------------------
+int dir_conv_variant_count(void) { return conv_variant_count(); }
+int dir_conv_variant_name(int variant, char* buf, int cap) {
+    if (variant < 0 || variant >= conv_variant_count() || !buf || cap <= 0)
+        return fail(DIR_ERR_INVALID, "variant_name: bad argument");
+    strncpy(buf, conv_variant(variant).name, cap - 1);
+    buf[cap - 1] = 0;
+    return DIR_OK;
+}
+
+static int fill_conv_args(ConvArgs& a, const void* x, const void* w, const float* bias,
+                          const void* res, void* y, int B, int H, int W, int Cin, int Cout, int R,
+                          int S, int stride, int pad, int OH, int OW, int relu) {
+    if (!x || !w || !bias || !y) return fail(DIR_ERR_INVALID, "conv: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||
+        pad < 0 || OH <= 0 || OW <= 0)
+        return fail(DIR_ERR_INVALID, "conv: bad dimension");
+    memset(&a, 0, sizeof(a));
+    a.x = (const uint16_t*)x;
+    a.w = (const uint16_t*)w;
+    a.bias = bias;
+    a.res = (const uint16_t*)res;
+    a.y = (uint16_t*)y;
+    a.zero = zero_page();
+    if (!a.zero) return fail(DIR_ERR_HIP, "conv: zero page allocation failed");
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.relu = relu ? 1 : 0;
+    a.M = B * OH * OW;
+    a.Ktot = R * S * Cin;
+    a.T = a.Ktot / 64;
+    return DIR_OK;
+}
+
+int dir_conv_bn_act(const void* x, const void* w, const float* bias, const void* res, void* y,
+                    int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                    int OH, int OW, int relu, int dtype, int variant, void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, x, w, bias, res, y, B, H, W, Cin, Cout, R, S, stride, pad, OH, OW, relu);
+    if (rc != DIR_OK) return rc;
+    return conv_launch(a, dtype, variant, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res, void* y,
+                          int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                          int OH, int OW, int relu, int dtype, void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, x, w, bias, res, y, B, H, W, Cin, Cout, R, S, stride, pad, OH, OW, relu);
+    if (rc != DIR_OK) return rc;
+    if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv: bad dtype");
+    return conv_launch_naive(a, dtype, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_prep_input(const void* img, int fmt, const float* mean3, const float* std3, void* out,
+                   int B, int H, int W, int dtype, void* stream) {
+    DIR_TRY
+    if (!img || !out || B <= 0 || H <= 0 || W <= 0) return fail(DIR_ERR_INVALID, "prep_input: bad argument");
+    return prep_input(img, fmt, mean3, std3, out, B, H, W, dtype, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    DIR_TRY
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(DIR_ERR_INVALID, "maxpool: bad argument");
+    return maxpool_3x3s2(x, y, B, H, W, C, dtype, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_global_pool(const void* x, float* out, int B, int H, int W, int C, int pooling, float p,
+                    float eps, float center_bias, int dtype, void* stream) {
+    DIR_TRY
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(DIR_ERR_INVALID, "global_pool: bad argument");
+    return global_pool(x, out, B, H, W, C, pooling, p, eps, center_bias, dtype, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream) {
+    DIR_TRY
+    if (!x || rows < 0 || cols <= 0) return fail(DIR_ERR_INVALID, "l2norm_rows: bad argument");
+    return l2norm_rows(x, rows, cols, eps, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
+                    int NQ, int K, const float* qsub, const float* bias, const float* alpha,
+                    void* stream) {
+    DIR_TRY
+    if (NP < 0 || NQ < 0) return fail(DIR_ERR_INVALID, "gemm_nt_f32: negative size");
+    if (NP == 0 || NQ == 0) return DIR_OK;
+    if (!P || !Q || !out) return fail(DIR_ERR_INVALID, "gemm_nt_f32: null pointer");
+    if (ldo < NP) return fail(DIR_ERR_INVALID, "gemm_nt_f32: ldo < NP");
+    return gemm_nt_f32(P, ldp, Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
+                        void* stream) {
+    DIR_TRY
+    if (!x || !out || N < 0 || D < 0) return fail(DIR_ERR_INVALID, "multiscale_pool: bad argument");
+    return multiscale_pool(x, out, S, N, D, mode, gemp, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// dir_common.h — shared device/host helpers for the gfx950 descriptor engine.
+// Written for MI355X (CDNA4) only: 64-lane wavefronts, MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/dir_engine.h"
+
+namespace dir {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define DIR_GLOBAL __attribute__((address_space(1)))
+#define DIR_LDS __attribute__((address_space(3)))
+
+// ---- thread-local error string ----------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define DIR_HIP_CHECK(expr)                                                                \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ::dir::fail(DIR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- 16-bit float conversions (host + device) ------------------------------------------------
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // RNE
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;  // RNE
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+__host__ __device__ inline float f16_bits_to_f32(uint16_t b) {
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+// Element-type policies for the 16-bit activation/weight formats.
+struct BF16 {
+    typedef bf16x8_t frag_t;
+    static constexpr int kDtype = DIR_BF16;
+    __host__ __device__ static inline float to_f32(uint16_t b) { return bf16_bits_to_f32(b); }
+    __host__ __device__ static inline uint16_t from_f32(float f) { return f32_to_bf16_bits(f); }
+    __device__ static inline f32x16_t mfma32(frag_t a, frag_t b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct FP16 {
+    typedef f16x8_t frag_t;
+    static constexpr int kDtype = DIR_FP16;
+    __host__ __device__ static inline float to_f32(uint16_t b) { return f16_bits_to_f32(b); }
+    __host__ __device__ static inline uint16_t from_f32(float f) { return f32_to_f16_bits(f); }
+    __device__ static inline f32x16_t mfma32(frag_t a, frag_t b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// Two packed 16-bit values <-> floats.
+template <class DT>
+__device__ inline void unpack2(uint32_t w, float& lo, float& hi) {
+    lo = DT::to_f32((uint16_t)(w & 0xffffu));
+    hi = DT::to_f32((uint16_t)(w >> 16));
+}
+template <class DT>
+__device__ inline uint32_t pack2(float lo, float hi) {
+    return (uint32_t)DT::from_f32(lo) | ((uint32_t)DT::from_f32(hi) << 16);
+}
+
+__device__ inline u32x4_t gload16(const void* p) {
+    return *(const DIR_GLOBAL u32x4_t*)p;
+}
+__device__ inline void gstore16(void* p, u32x4_t v) {
+    *(DIR_GLOBAL u32x4_t*)p = v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; give each
+// XCD a contiguous run of logical tiles so neighbouring tiles (which share an operand panel) hit
+// the same 4 MiB L2.  Placement only affects speed, never results.
+__device__ inline int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace dir

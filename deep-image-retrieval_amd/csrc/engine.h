@@ -1,0 +1,76 @@
+// engine.h — model graph, weight packing and the forward pass of ResNet_RMAC on one MI355X.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv_igemm.h"
+#include "pointwise.h"
+
+namespace dir {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvLayer {
+    std::string name;     // "layer3.4.conv2", "conv1", "layer2.0.downsample"
+    std::string wkey;     // state-dict key of the conv weight
+    std::string bnprefix; // state-dict prefix of its BatchNorm ("layer3.4.bn2")
+    int Cin = 0, Cout = 0, R = 1, S = 1, stride = 1, pad = 0;
+    bool relu = false;
+    bool stem = false;    // packed as the 4x4 s1 space-to-depth form (Cin 16)
+    uint16_t* d_w = nullptr;
+    float* d_bias = nullptr;
+    std::map<long, int> tuned;  // M -> variant index chosen by autotune
+};
+
+struct BlockDef {
+    int conv1 = -1, conv2 = -1, conv3 = -1, down = -1;
+    int stride = 1;
+};
+
+struct ProfSlot {
+    hipEvent_t start, stop;
+    std::string name, kernel;
+    double flops, bytes;
+};
+
+struct Plan {  // byte offsets into the caller's workspace for one (B, H, W)
+    size_t s2d, stem, bufA, bufB, t1, t2, ds, pooled, fcout, total;
+    int H2, W2, OH1, OW1, PH, PW;
+};
+
+}  // namespace dir
+
+struct dir_engine {
+    dir_model_desc desc;
+    int device = 0;
+    int dtype = DIR_BF16;
+    bool finalized = false;
+    std::map<std::string, dir::HostTensor> state;
+    std::vector<dir::ConvLayer> convs;
+    std::vector<dir::BlockDef> blocks;
+    int feat_dim = 0;  // trunk channels (512 * expansion)
+    float gem_p = 3.f;
+    float* d_fc_w = nullptr;
+    float* d_fc_b = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<dir::ProfSlot> prof;
+    size_t prof_used = 0;
+    bool tuning = false;
+
+    int build_graph();
+    int finalize(int dtype);
+    int plan(int B, int H, int W, dir::Plan* p) const;
+    int forward(const void* img, int B, int H, int W, int fmt, float* desc_out, void* feat_out,
+                int* fh, int* fw, int* fc, void* ws, size_t ws_bytes, hipStream_t stream);
+    int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
+                 int H, int W, int OH, int OW, hipStream_t stream);
+    int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
+                   hipStream_t stream);
+    int prof_end(hipStream_t stream);
+    void release();
+};

@@ -1,0 +1,491 @@
+// engine.hip — ResNet_RMAC descriptor extraction on one MI355X.
+//
+// What the reference does in Python with torch.nn modules
+//   ResNet.forward        dirtorch/nets/backbones/resnet.py:157-174
+//   Bottleneck.forward    dirtorch/nets/backbones/resnet.py:67-87   (BasicBlock :29-44)
+//   ResNet_RMAC.forward   dirtorch/nets/rmac_resnet.py:39-69
+// becomes a fixed launch sequence over caller-owned workspace:
+//   prep (s2d) -> stem conv(+BN+ReLU) -> maxpool -> [bottleneck: 1x1 -> 3x3(s) -> 1x1 (+ds) +res +ReLU]*
+//   -> global pool (GeM/max/avg, fp32) -> (L2) -> FC (fp32 MFMA) -> L2.
+// Eval-mode BatchNorm (eps 1e-5) is folded into the conv weights and a per-channel fp32 bias at
+// finalize(); activations stay NHWC 16-bit between kernels, every reduction is fp32.
+#include "engine.h"
+
+#include <math.h>
+#include <algorithm>
+
+namespace dir {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+const char* last_error() { return g_err.c_str(); }
+
+static uint16_t* g_zero = nullptr;
+const uint16_t* zero_page() {
+    if (!g_zero) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        g_zero = (uint16_t*)p;
+    }
+    return g_zero;
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Deterministic noise in [-1, 1) for autotune inputs (no host RNG, no cuRAND analogue needed).
+__global__ void fill_noise_kernel(uint16_t* p, long n, int dtype) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)i * 2654435761u + 12345u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    const float f = (float)(h & 0xffff) / 32768.f - 1.f;
+    p[i] = dtype == DIR_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f);
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+// ---- graph ------------------------------------------------------------------------------------
+int dir_engine::build_graph() {
+    convs.clear();
+    blocks.clear();
+    const int expansion = desc.bottleneck ? 4 : 1;
+    auto add_conv = [&](const std::string& name, const std::string& wkey, const std::string& bn,
+                        int cin, int cout, int k, int stride, int pad, bool relu) {
+        ConvLayer L;
+        L.name = name;
+        L.wkey = wkey;
+        L.bnprefix = bn;
+        L.Cin = cin;
+        L.Cout = cout;
+        L.R = L.S = k;
+        L.stride = stride;
+        L.pad = pad;
+        L.relu = relu;
+        convs.push_back(L);
+        return (int)convs.size() - 1;
+    };
+    // stem: 7x7 s2 p3, 3 -> 64 (resnet.py:115-118); executed as 4x4 s1 over the s2d image.
+    {
+        int i = add_conv("conv1", "conv1.weight", "bn1", 3, 64, 7, 2, 3, true);
+        convs[i].stem = true;
+    }
+    int inplanes = 64;
+    const int planes_of[4] = {64, 128, 256, 512};
+    for (int s = 0; s < 4; ++s) {
+        const int planes = planes_of[s];
+        const int nblk = desc.layers[s];
+        if (nblk <= 0) return fail(DIR_ERR_INVALID, "model desc: layers[] must be positive");
+        for (int j = 0; j < nblk; ++j) {
+            const int stride = (j == 0 && s > 0) ? 2 : 1;
+            const std::string pre = "layer" + std::to_string(s + 1) + "." + std::to_string(j);
+            BlockDef bd;
+            bd.stride = stride;
+            if (desc.bottleneck) {
+                bd.conv1 = add_conv(pre + ".conv1", pre + ".conv1.weight", pre + ".bn1", inplanes,
+                                    planes, 1, 1, 0, true);
+                bd.conv2 = add_conv(pre + ".conv2", pre + ".conv2.weight", pre + ".bn2", planes,
+                                    planes, 3, stride, 1, true);
+                bd.conv3 = add_conv(pre + ".conv3", pre + ".conv3.weight", pre + ".bn3", planes,
+                                    planes * 4, 1, 1, 0, true);  // ReLU after the residual add
+            } else {
+                bd.conv1 = add_conv(pre + ".conv1", pre + ".conv1.weight", pre + ".bn1", inplanes,
+                                    planes, 3, stride, 1, true);
+                bd.conv2 = add_conv(pre + ".conv2", pre + ".conv2.weight", pre + ".bn2", planes,
+                                    planes, 3, 1, 1, true);  // ReLU after the residual add
+            }
+            if (j == 0 && (stride != 1 || inplanes != planes * expansion)) {
+                // resnet.py:134-141: 1x1 conv (stride) + BN, no ReLU
+                bd.down = add_conv(pre + ".downsample", pre + ".downsample.0.weight",
+                                   pre + ".downsample.1", inplanes, planes * expansion, 1, stride, 0,
+                                   false);
+            }
+            inplanes = planes * expansion;
+            blocks.push_back(bd);
+        }
+    }
+    feat_dim = inplanes;
+    return DIR_OK;
+}
+
+// ---- weights ------------------------------------------------------------------------------------
+static const HostTensor* find(const std::map<std::string, HostTensor>& st, const std::string& k) {
+    auto it = st.find(k);
+    return it == st.end() ? nullptr : &it->second;
+}
+
+int dir_engine::finalize(int dt) {
+    if (dt != DIR_BF16 && dt != DIR_FP16) return fail(DIR_ERR_INVALID, "finalize: bad dtype");
+    DIR_HIP_CHECK(hipSetDevice(device));
+    release();
+    dtype = dt;
+    auto to16 = [&](float f) { return dt == DIR_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f); };
+
+    for (ConvLayer& L : convs) {
+        const HostTensor* w = find(state, L.wkey);
+        const HostTensor* g = find(state, L.bnprefix + ".weight");
+        const HostTensor* bt = find(state, L.bnprefix + ".bias");
+        const HostTensor* mu = find(state, L.bnprefix + ".running_mean");
+        const HostTensor* var = find(state, L.bnprefix + ".running_var");
+        if (!w) return fail(DIR_ERR_MISSING, "missing tensor " + L.wkey);
+        if (!g || !bt || !mu || !var)
+            return fail(DIR_ERR_MISSING, "missing BatchNorm tensors " + L.bnprefix + ".*");
+        const int64_t want[4] = {L.Cout, L.Cin, L.R, L.S};
+        if (w->shape.size() != 4 || !std::equal(want, want + 4, w->shape.begin()))
+            return fail(DIR_ERR_INVALID, "bad shape for " + L.wkey);
+        if ((int)g->data.size() != L.Cout || (int)bt->data.size() != L.Cout ||
+            (int)mu->data.size() != L.Cout || (int)var->data.size() != L.Cout)
+            return fail(DIR_ERR_INVALID, "bad BatchNorm shape for " + L.bnprefix);
+
+        std::vector<float> scale(L.Cout), bias(L.Cout);
+        for (int o = 0; o < L.Cout; ++o) {
+            // BatchNorm2d eval: y = (x - mean) / sqrt(var + eps) * gamma + beta, eps = 1e-5
+            const float inv = 1.0f / sqrtf(var->data[o] + 1e-5f);
+            scale[o] = g->data[o] * inv;
+            bias[o] = bt->data[o] - mu->data[o] * scale[o];
+        }
+        std::vector<uint16_t> packed;
+        if (L.stem) {
+            // 7x7 s2 p3 over 3 channels == 4x4 s1 (pad 2 top/left) over the 2x2 space-to-depth
+            // image with 12 (+4 zero) channels: tap r = 2R + dy - 1, s = 2S + dx - 1.
+            packed.assign((size_t)L.Cout * 4 * 4 * 16, 0);
+            for (int o = 0; o < L.Cout; ++o)
+                for (int R = 0; R < 4; ++R)
+                    for (int S = 0; S < 4; ++S)
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int r = 2 * R + dy - 1, s = 2 * S + dx - 1;
+                                if (r < 0 || s < 0 || r >= 7 || s >= 7) continue;
+                                for (int c = 0; c < 3; ++c) {
+                                    const float v =
+                                        w->data[(((size_t)o * 3 + c) * 7 + r) * 7 + s] * scale[o];
+                                    packed[(((size_t)o * 4 + R) * 4 + S) * 16 + (dy * 2 + dx) * 3 + c] =
+                                        to16(v);
+                                }
+                            }
+        } else {
+            packed.resize((size_t)L.Cout * L.R * L.S * L.Cin);
+            for (int o = 0; o < L.Cout; ++o)
+                for (int c = 0; c < L.Cin; ++c)
+                    for (int r = 0; r < L.R; ++r)
+                        for (int s = 0; s < L.S; ++s) {
+                            const float v =
+                                w->data[(((size_t)o * L.Cin + c) * L.R + r) * L.S + s] * scale[o];
+                            packed[(((size_t)o * L.R + r) * L.S + s) * L.Cin + c] = to16(v);
+                        }
+        }
+        DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed.size() * 2));
+        DIR_HIP_CHECK(hipMemcpy(L.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+        DIR_HIP_CHECK(hipMalloc((void**)&L.d_bias, L.Cout * 4));
+        DIR_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), L.Cout * 4, hipMemcpyHostToDevice));
+        L.tuned.clear();
+    }
+
+    if (desc.pooling == DIR_POOL_GEM) {
+        const HostTensor* p = find(state, "adpool.p");
+        if (!p || p->data.empty()) return fail(DIR_ERR_MISSING, "missing tensor adpool.p");
+        gem_p = p->data[0];
+        if (!(gem_p > 0.f)) return fail(DIR_ERR_INVALID, "adpool.p must be positive");
+    }
+    if (!desc.without_fc) {
+        const HostTensor* fw = find(state, "fc.weight");
+        const HostTensor* fb = find(state, "fc.bias");
+        if (!fw || !fb) return fail(DIR_ERR_MISSING, "missing tensor fc.weight / fc.bias");
+        if (fw->shape.size() != 2 || fw->shape[0] != desc.out_dim || fw->shape[1] != feat_dim ||
+            (int)fb->data.size() != desc.out_dim)
+            return fail(DIR_ERR_INVALID, "bad shape for fc.weight / fc.bias");
+        DIR_HIP_CHECK(hipMalloc((void**)&d_fc_w, fw->data.size() * 4));
+        DIR_HIP_CHECK(hipMemcpy(d_fc_w, fw->data.data(), fw->data.size() * 4, hipMemcpyHostToDevice));
+        DIR_HIP_CHECK(hipMalloc((void**)&d_fc_b, fb->data.size() * 4));
+        DIR_HIP_CHECK(hipMemcpy(d_fc_b, fb->data.data(), fb->data.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!zero_page()) return fail(DIR_ERR_HIP, "could not allocate the zero page");
+    DIR_HIP_CHECK(hipDeviceSynchronize());
+    finalized = true;
+    return DIR_OK;
+}
+
+void dir_engine::release() {
+    for (ConvLayer& L : convs) {
+        if (L.d_w) (void)hipFree(L.d_w);
+        if (L.d_bias) (void)hipFree(L.d_bias);
+        L.d_w = nullptr;
+        L.d_bias = nullptr;
+    }
+    if (d_fc_w) (void)hipFree(d_fc_w);
+    if (d_fc_b) (void)hipFree(d_fc_b);
+    d_fc_w = d_fc_b = nullptr;
+    finalized = false;
+}
+
+// ---- workspace plan ---------------------------------------------------------------------------
+static inline int conv_out(int h, int k, int stride, int pad) { return (h + 2 * pad - k) / stride + 1; }
+
+int dir_engine::plan(int B, int H, int W, Plan* p) const {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(DIR_ERR_INVALID, "forward: B, H, W must be positive");
+    if (H < 7 || W < 7) return fail(DIR_ERR_INVALID, "forward: image smaller than the 7x7 stem");
+    p->H2 = (H + 1) / 2;
+    p->W2 = (W + 1) / 2;
+    p->OH1 = conv_out(H, 7, 2, 3);
+    p->OW1 = conv_out(W, 7, 2, 3);
+    p->PH = conv_out(p->OH1, 3, 2, 1);
+    p->PW = conv_out(p->OW1, 3, 2, 1);
+    size_t io = 0, t1 = 0, t2 = 0, ds = 0;
+    int h = p->PH, w = p->PW;
+    io = (size_t)B * h * w * 64 * 2;
+    for (const BlockDef& bd : blocks) {
+        const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
+        const ConvLayer& c1 = convs[bd.conv1];
+        const ConvLayer& cl = convs[desc.bottleneck ? bd.conv3 : bd.conv2];
+        if (desc.bottleneck) {
+            t1 = std::max(t1, (size_t)B * h * w * c1.Cout * 2);
+            t2 = std::max(t2, (size_t)B * oh * ow * convs[bd.conv2].Cout * 2);
+        } else {
+            t1 = std::max(t1, (size_t)B * oh * ow * c1.Cout * 2);
+        }
+        if (bd.down >= 0) ds = std::max(ds, (size_t)B * oh * ow * convs[bd.down].Cout * 2);
+        io = std::max(io, (size_t)B * oh * ow * cl.Cout * 2);
+        h = oh;
+        w = ow;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    p->s2d = take((size_t)B * p->H2 * p->W2 * 16 * 2);
+    p->stem = take((size_t)B * p->OH1 * p->OW1 * 64 * 2);
+    p->bufA = take(io);
+    p->bufB = take(io);
+    p->t1 = take(t1);
+    p->t2 = take(t2 ? t2 : 256);
+    p->ds = take(ds ? ds : 256);
+    p->pooled = take((size_t)B * feat_dim * 4);
+    p->fcout = take((size_t)B * std::max(desc.out_dim, feat_dim) * 4);
+    p->total = off;
+    return DIR_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+int dir_engine::prof_begin(const std::string& name, const std::string& kernel, double flops,
+                           double bytes, hipStream_t stream) {
+    if (!profiling) return DIR_OK;
+    if (prof_used == prof.size()) {
+        ProfSlot s;
+        DIR_HIP_CHECK(hipEventCreate(&s.start));
+        DIR_HIP_CHECK(hipEventCreate(&s.stop));
+        prof.push_back(s);
+    }
+    ProfSlot& s = prof[prof_used];
+    s.name = name;
+    s.kernel = kernel;
+    s.flops = flops;
+    s.bytes = bytes;
+    DIR_HIP_CHECK(hipEventRecord(s.start, stream));
+    return DIR_OK;
+}
+int dir_engine::prof_end(hipStream_t stream) {
+    if (!profiling) return DIR_OK;
+    DIR_HIP_CHECK(hipEventRecord(prof[prof_used].stop, stream));
+    ++prof_used;
+    return DIR_OK;
+}
+
+// ---- one convolution ----------------------------------------------------------------------------
+int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
+                         int H, int W, int OH, int OW, hipStream_t stream) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w = L.d_w;
+    a.bias = L.d_bias;
+    a.res = res;
+    a.y = y;
+    a.zero = zero_page();
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.OH = OH;
+    a.OW = OW;
+    a.Cout = L.Cout;
+    if (L.stem) {  // (H, W) is the space-to-depth grid here
+        a.Cin = 16;
+        a.R = a.S = 4;
+        a.stride = 1;
+        a.pad = 2;
+    } else {
+        a.Cin = L.Cin;
+        a.R = L.R;
+        a.S = L.S;
+        a.stride = L.stride;
+        a.pad = L.pad;
+    }
+    a.relu = L.relu ? 1 : 0;
+    a.M = B * OH * OW;
+    a.Ktot = a.R * a.S * a.Cin;
+    a.T = a.Ktot / 64;
+    const double macs = (double)a.M * L.Cout * (double)(L.R * L.S * L.Cin);  // true taps (stem: 147)
+    const double bytes = 2.0 * ((double)B * H * W * a.Cin + (double)a.M * L.Cout * (res ? 2 : 1) +
+                                (double)L.Cout * a.Ktot);
+
+    int variant = -1;
+    auto it = L.tuned.find(a.M);
+    if (it != L.tuned.end()) variant = it->second;
+    if (tuning && it == L.tuned.end()) {
+        // time every admissible variant on the live input, keep the fastest
+        hipEvent_t e0, e1;
+        DIR_HIP_CHECK(hipEventCreate(&e0));
+        DIR_HIP_CHECK(hipEventCreate(&e1));
+        float best = 1e30f;
+        for (int v = 0; v < conv_variant_count(); ++v) {
+            if (!conv_variant_admissible(v, a)) continue;
+            int rc = conv_launch(a, dtype, v, stream);  // warm-up (also sets func attributes)
+            if (rc != DIR_OK) return rc;
+            DIR_HIP_CHECK(hipEventRecord(e0, stream));
+            for (int rep = 0; rep < 3; ++rep) {
+                rc = conv_launch(a, dtype, v, stream);
+                if (rc != DIR_OK) return rc;
+            }
+            DIR_HIP_CHECK(hipEventRecord(e1, stream));
+            DIR_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            DIR_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) {
+                best = ms;
+                variant = v;
+            }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        L.tuned[a.M] = variant;
+    }
+    if (variant < 0) variant = conv_pick_variant(a);
+    int rc = prof_begin(L.name, std::string("conv_igemm<") + conv_variant(variant).name + ">",
+                        2.0 * macs, bytes, stream);
+    if (rc != DIR_OK) return rc;
+    rc = conv_launch(a, dtype, variant, stream);
+    if (rc != DIR_OK) return rc;
+    return prof_end(stream);
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* desc_out,
+                        void* feat_out, int* fh, int* fw, int* fc, void* ws, size_t ws_bytes,
+                        hipStream_t stream) {
+    if (!finalized) return fail(DIR_ERR_STATE, "forward before finalize");
+    Plan p;
+    int rc = plan(B, H, W, &p);
+    if (rc != DIR_OK) return rc;
+    if (!ws || ws_bytes < p.total)
+        return fail(DIR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(p.total) +
+                                           " bytes, got " + std::to_string(ws_bytes));
+    if (((uintptr_t)ws & 255) != 0) return fail(DIR_ERR_INVALID, "workspace must be 256-byte aligned");
+    char* base = (char*)ws;
+    uint16_t* s2d = (uint16_t*)(base + p.s2d);
+    uint16_t* stem = (uint16_t*)(base + p.stem);
+    uint16_t* cur = (uint16_t*)(base + p.bufA);
+    uint16_t* nxt = (uint16_t*)(base + p.bufB);
+    uint16_t* t1 = (uint16_t*)(base + p.t1);
+    uint16_t* t2 = (uint16_t*)(base + p.t2);
+    uint16_t* ds = (uint16_t*)(base + p.ds);
+    float* pooled = (float*)(base + p.pooled);
+    float* fcout = (float*)(base + p.fcout);
+
+    // 1. image -> space-to-depth NHWC16
+    if (img) {
+        rc = prof_begin("prep_input", "prep_input", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
+                        (double)B * p.H2 * p.W2 * 32, stream);
+        if (rc != DIR_OK) return rc;
+        rc = prep_input(img, fmt, desc.mean, desc.std, s2d, B, H, W, dtype, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    } else {  // autotune: synthetic noise straight into the s2d buffer
+        const long n = (long)B * p.H2 * p.W2 * 16;
+        hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           s2d, n, dtype);
+        DIR_HIP_CHECK(hipGetLastError());
+    }
+    // 2. stem + maxpool
+    rc = run_conv(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
+    if (rc != DIR_OK) return rc;
+    rc = prof_begin("maxpool", "maxpool_3x3s2", 0,
+                    2.0 * ((double)B * p.OH1 * p.OW1 * 64 + (double)B * p.PH * p.PW * 64), stream);
+    if (rc != DIR_OK) return rc;
+    rc = maxpool_3x3s2(stem, cur, B, p.OH1, p.OW1, 64, dtype, stream);
+    if (rc != DIR_OK) return rc;
+    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+
+    // 3. residual stages
+    int h = p.PH, w = p.PW;
+    for (BlockDef& bd : blocks) {
+        const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
+        const uint16_t* resid = cur;
+        if (bd.down >= 0) {
+            rc = run_conv(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            resid = ds;
+        }
+        if (desc.bottleneck) {
+            rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv(convs[bd.conv2], t1, nullptr, t2, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+        } else {
+            rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv(convs[bd.conv2], t1, resid, nxt, B, oh, ow, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+        }
+        std::swap(cur, nxt);
+        h = oh;
+        w = ow;
+    }
+    if (feat_out) {
+        DIR_HIP_CHECK(hipMemcpyAsync(feat_out, cur, (size_t)B * h * w * feat_dim * 2,
+                                     hipMemcpyDeviceToDevice, stream));
+        if (fh) *fh = h;
+        if (fw) *fw = w;
+        if (fc) *fc = feat_dim;
+    }
+    if (!desc_out) return DIR_OK;
+
+    // 4. head: global pool -> (L2) -> FC -> L2   (rmac_resnet.py:58-68)
+    rc = prof_begin("adpool", "global_pool", 0, (double)B * h * w * feat_dim * 2 + (double)B * feat_dim * 4,
+                    stream);
+    if (rc != DIR_OK) return rc;
+    rc = global_pool(cur, pooled, B, h, w, feat_dim, desc.pooling, gem_p, 1e-6f, desc.center_bias,
+                     dtype, stream);
+    if (rc != DIR_OK) return rc;
+    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    if (desc.norm_features) {
+        rc = l2norm_rows(pooled, B, feat_dim, 1e-12f, stream);
+        if (rc != DIR_OK) return rc;
+    }
+    const int D = desc.without_fc ? feat_dim : desc.out_dim;
+    if (!desc.without_fc) {
+        rc = prof_begin("fc", "gemm_nt_f32", 2.0 * B * feat_dim * (double)D,
+                        4.0 * ((double)D * feat_dim + (double)B * (feat_dim + D)), stream);
+        if (rc != DIR_OK) return rc;
+        rc = gemm_nt_f32(d_fc_w, feat_dim, pooled, feat_dim, fcout, D, D, B, feat_dim, nullptr,
+                         d_fc_b, nullptr, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    } else {
+        fcout = pooled;
+    }
+    rc = l2norm_rows(fcout, B, D, 1e-12f, stream);
+    if (rc != DIR_OK) return rc;
+    DIR_HIP_CHECK(hipMemcpyAsync(desc_out, fcout, (size_t)B * D * 4, hipMemcpyDeviceToDevice, stream));
+    return DIR_OK;
+}

@@ -1,0 +1,177 @@
+// gemm_f32.hip — exact-fp32 "NT" GEMM on the matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+//
+//   out[j][i] = alpha[i] * sum_k P[i][k] * (Q[j][k] - qsub[k]) + bias[i]
+//
+// One kernel serves the three fp32 contractions of the descriptor path:
+//   FC "whitening"   P = fc.weight [D_out, 2048], Q = pooled features [B, 2048], bias = fc.bias
+//                    (dirtorch/nets/rmac_resnet.py:34,66)
+//   PCA whitening    P = components_[:v], Q = descriptors, qsub = mean_, alpha = 1/(m * var^p)
+//                    (dirtorch/utils/common.py:221-232)
+//   similarity       P = database descriptors [N, D], Q = queries [Q, D]  -> scores [Q, N]
+//                    (dirtorch/utils/common.py:30-38)
+// The f32 MFMA is bit-for-bit a k-ordered fmaf chain, so results are fp32-exact up to summation
+// order.  P is the long operand: 128 P rows per workgroup, one 32-row strip per wave; all of a
+// Q tile (32*TJ rows) is shared by the four waves.  The similarity case is HBM-bound on P
+// (N*D*4 bytes read once); the tile loop keeps two K-slabs of 32 floats in LDS (register staged
+// so that `- qsub[k]` and the K tail are folded into the staging pass).
+#include "dir_common.h"
+#include "pointwise.h"
+
+namespace dir {
+
+template <int TJ>
+__global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restrict__ P, int ldp,
+                                                         const float* __restrict__ Q, int ldq,
+                                                         float* __restrict__ out, int ldo, int NP,
+                                                         int NQ, int K,
+                                                         const float* __restrict__ qsub,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ alpha,
+                                                         int tiles_i) {
+    constexpr int BI = 128, BJ = 32 * TJ;
+    constexpr int PS = BI * 128;              // bytes of one P slab (128 rows x 32 floats)
+    constexpr int STAGE_BYTES = (BI + BJ) * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_i = wg % tiles_i;  // i fastest: consecutive blocks of an XCD share the Q tile
+    const int tile_j = wg / tiles_i;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
+
+    const int slot = tid & 7;
+    const int srcchunk = slot ^ ((tid >> 4) & 7);  // 16-byte chunk (4 floats) of the 128-byte row
+    const int prow = tid >> 3;                     // + 32 * i
+
+    f32x4_t pr[4], qr[TJ];
+    auto fetch = [&](int k0) {
+        const int k = k0 + srcchunk * 4;
+        const bool kok = k < K;  // K % 4 == 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i0 + i * 32 + prow;
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (kok && row < NP) v = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)row * ldp + k);
+            pr[i] = v;
+        }
+        f32x4_t sub = {0.f, 0.f, 0.f, 0.f};
+        if (qsub && kok) sub = *(const DIR_GLOBAL f32x4_t*)(qsub + k);
+#pragma unroll
+        for (int i = 0; i < TJ; ++i) {
+            const int row = j0 + i * 32 + prow;
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            if (kok && row < NQ) v = *(const DIR_GLOBAL f32x4_t*)(Q + (size_t)row * ldq + k) - sub;
+            qr[i] = v;
+        }
+    };
+    auto commit = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4_t*)(stage + (i * 256 + tid) * 16) = pr[i];
+#pragma unroll
+        for (int i = 0; i < TJ; ++i) *(f32x4_t*)(stage + PS + (i * 256 + tid) * 16) = qr[i];
+    };
+
+    const int lrow = lane & 31, lhi = lane >> 5, lswz = (lane >> 1) & 7;
+    int loff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) loff[c] = lrow * 128 + (((2 * c + lhi) ^ lswz) << 4);
+    const int pbase = (wave * 32) * 128;
+
+    f32x16_t acc[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    auto compute = [&](const char* stage) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4_t pf = *(const f32x4_t*)(stage + pbase + loff[c]);
+            f32x4_t qf[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) qf[j] = *(const f32x4_t*)(stage + PS + j * 4096 + loff[c]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[q], qf[j][q], acc[j], 0, 0, 0);
+        }
+    };
+
+    const int T = (K + 31) / 32;
+    char* stage0 = smem;
+    char* stage1 = smem + STAGE_BYTES;
+    fetch(0);
+    commit(stage0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        char* cur = (t & 1) ? stage1 : stage0;
+        char* nxt = (t & 1) ? stage0 : stage1;
+        const bool more = t + 1 < T;
+        if (more) fetch((t + 1) * 32);
+        compute(cur);
+        if (more) commit(nxt);
+        __syncthreads();
+    }
+
+    // D[i][j]: lane holds column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + 0..3 for g = 0..3
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int jj = j0 + j * 32 + lrow;
+        if (jj >= NQ) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ii = i0 + wave * 32 + 8 * g + 4 * lhi;
+            float v[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ii + e < NP) {
+                    float r = v[e];
+                    if (alpha) r *= alpha[ii + e];
+                    if (bias) r += bias[ii + e];
+                    v[e] = r;
+                }
+            }
+            float* dst = out + (size_t)jj * ldo + ii;
+            if (ii + 3 < NP && ((ldo & 3) == 0)) {
+                *(DIR_GLOBAL f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ii + e < NP) dst[e] = v[e];
+            }
+        }
+    }
+}
+
+int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
+                int NQ, int K, const float* qsub, const float* bias, const float* alpha,
+                hipStream_t stream) {
+    if (NP <= 0 || NQ <= 0) return DIR_OK;
+    if (K <= 0 || (K & 3) || (ldp & 3) || (ldq & 3))
+        return fail(DIR_ERR_INVALID, "gemm_nt_f32: K, ldp, ldq must be positive multiples of 4");
+    if (((uintptr_t)P & 15) || ((uintptr_t)Q & 15) || ((uintptr_t)out & 15) ||
+        (qsub && ((uintptr_t)qsub & 15)))
+        return fail(DIR_ERR_INVALID, "gemm_nt_f32: operands must be 16-byte aligned");
+    const int tiles_i = ceil_div(NP, 128);
+    // Q tile: as wide as needed up to 128 rows, then loop tiles over j.
+    int tj = NQ >= 97 ? 4 : (NQ >= 65 ? 3 : (NQ >= 33 ? 2 : 1));
+    const int tiles_j = ceil_div(NQ, 32 * tj);
+    const long nblk = (long)tiles_i * tiles_j;
+    if (nblk >= (1L << 31)) return fail(DIR_ERR_INVALID, "gemm_nt_f32: grid too large");
+#define DIR_G(TJ)                                                                              \
+    hipLaunchKernelGGL(gemm_nt_f32_kernel<TJ>, dim3((unsigned)nblk), dim3(256), 0, stream, P,  \
+                       ldp, Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, tiles_i)
+    switch (tj) {
+        case 1: DIR_G(1); break;
+        case 2: DIR_G(2); break;
+        case 3: DIR_G(3); break;
+        default: DIR_G(4); break;
+    }
+#undef DIR_G
+    DIR_HIP_CHECK(hipGetLastError());
+    return DIR_OK;
+}
+
+}  // namespace dir

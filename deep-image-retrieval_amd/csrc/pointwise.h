@@ -1,0 +1,19 @@
+// pointwise.h — launchers of the HBM-bound kernels (pointwise.hip) and the fp32 NT GEMM (gemm_f32.hip).
+#pragma once
+#include "dir_common.h"
+
+namespace dir {
+
+int prep_input(const void* img, int fmt, const float* mean3, const float* std3, void* out, int B,
+               int H, int W, int dtype, hipStream_t stream);
+int maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t stream);
+int global_pool(const void* x, float* out, int B, int H, int W, int C, int pooling, float p,
+                float eps, float center_bias, int dtype, hipStream_t stream);
+int l2norm_rows(float* x, int rows, int cols, float eps, hipStream_t stream);
+int multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
+                    hipStream_t stream);
+int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
+                int NQ, int K, const float* qsub, const float* bias, const float* alpha,
+                hipStream_t stream);
+
+}  // namespace dir

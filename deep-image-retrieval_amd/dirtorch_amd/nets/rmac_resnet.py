@@ -1,0 +1,309 @@
+"""ResNet_RMAC on the MI355X engine - host-side mirror of dirtorch/nets/rmac_resnet.py:12-88.
+
+The object duck-types what the reference's callers touch (dirtorch/test_dir.py:57-81,183-191):
+state_dict()/load_state_dict() with the reference key names, eval(), cuda(), preprocess, iscuda,
+pca, rgb_means/rgb_stds/input_size, and __call__(x[B,3,H,W]) -> unit-norm descriptors [B,D]
+(shape [D] when B == 1, like the reference's squeeze_, rmac_resnet.py:64).
+
+It is NOT a torch.nn.Module: there is no torch compute graph behind it.  Weights live in a host
+state dict and, packed, inside the C engine (include/dir_engine.h); forward is one dir_forward call.
+"""
+import ctypes
+import math
+import os
+from collections import OrderedDict
+
+import torch
+
+from .. import _lib
+from .._lib import ModelDesc, POOLING, call, ptr, stream_ptr
+
+_ARCH = {  # name -> (bottleneck, layers)   dirtorch/nets/rmac_resnet.py:74-88
+    'resnet18': (0, [2, 2, 2, 2]),
+    'resnet50': (1, [3, 4, 6, 3]),
+    'resnet101': (1, [3, 4, 23, 3]),
+    'resnet152': (1, [3, 8, 36, 3]),
+}
+
+
+def _default_dtype():
+    name = os.environ.get('DIRTORCH_AMD_DTYPE', 'bf16').lower()
+    if name not in ('bf16', 'fp16'):
+        raise ValueError("DIRTORCH_AMD_DTYPE must be 'bf16' or 'fp16'")
+    return name
+
+
+class ResNet_RMAC(object):
+    """ResNet trunk + global pooling + FC + L2 (without ROI pooling), engine-backed."""
+
+    def __init__(self, model_name, out_dim=2048, norm_features=False, pooling='gem', gemp=3,
+                 center_bias=0, dropout_p=None, without_fc=False, **kwargs):
+        if kwargs:
+            # the reference forwards unknown kwargs to ResNet.__init__ and dies with TypeError there
+            raise TypeError('unexpected keyword arguments: %s' % sorted(kwargs))
+        if not (pooling == 'max' or pooling == 'avg' or pooling.startswith('gem')):
+            raise ValueError(pooling)  # rmac_resnet.py:31
+        self.model_name = model_name
+        self.bottleneck, self.layers = _ARCH[model_name]
+        self.expansion = 4 if self.bottleneck else 1
+        self.rgb_means = [0.485, 0.456, 0.406]   # resnet.py:110-112
+        self.rgb_stds = [0.229, 0.224, 0.225]
+        self.input_size = (3, 224, 224)
+        self.norm_features = norm_features
+        self.without_fc = without_fc
+        self.pooling = pooling
+        self.center_bias = center_bias
+        self.dropout_p = dropout_p        # identity in eval mode (rmac_resnet.py:44-45)
+        self.out_dim = out_dim
+        self.feat_dim = out_dim
+        self.fc_name = 'fc'
+        self.iscuda = False
+        self.pca = None
+        self.training = False
+        self.compute_dtype = _default_dtype()
+        self._gemp = float(gemp)
+        self._state = self._init_state()
+        self._engine = None
+        self._dirty = True
+        self._ws = None
+        self._tuned = set()
+        self.autotune = os.environ.get('DIRTORCH_AMD_AUTOTUNE', '0') == '1'
+
+    # ---- parameters ------------------------------------------------------------------------
+    def _conv_specs(self):
+        """(weight key, bn prefix, Cout, Cin, k) in state-dict order of the reference module."""
+        specs = [('conv1.weight', 'bn1', 64, 3, 7)]
+        inplanes = 64
+        for s, planes in enumerate((64, 128, 256, 512)):
+            for j in range(self.layers[s]):
+                pre = 'layer%d.%d' % (s + 1, j)
+                stride = 2 if (j == 0 and s > 0) else 1
+                if self.bottleneck:
+                    specs += [(pre + '.conv1.weight', pre + '.bn1', planes, inplanes, 1),
+                              (pre + '.conv2.weight', pre + '.bn2', planes, planes, 3),
+                              (pre + '.conv3.weight', pre + '.bn3', planes * 4, planes, 1)]
+                else:
+                    specs += [(pre + '.conv1.weight', pre + '.bn1', planes, inplanes, 3),
+                              (pre + '.conv2.weight', pre + '.bn2', planes, planes, 3)]
+                if j == 0 and (stride != 1 or inplanes != planes * self.expansion):
+                    specs.append((pre + '.downsample.0.weight', pre + '.downsample.1',
+                                  planes * self.expansion, inplanes, 1))
+                inplanes = planes * self.expansion
+        self.trunk_dim = inplanes
+        return specs
+
+    def _init_state(self):
+        """Fresh parameters with the reference's initialisation (resnet.py:92-99 reset_weights;
+        nn.Linear default init for fc); values are random, the key set and shapes are exact."""
+        sd = OrderedDict()
+        for wkey, bn, cout, cin, k in self._conv_specs():
+            n = k * k * cout
+            sd[wkey] = torch.randn(cout, cin, k, k) * math.sqrt(2. / n)
+            sd[bn + '.weight'] = torch.ones(cout)
+            sd[bn + '.bias'] = torch.zeros(cout)
+            sd[bn + '.running_mean'] = torch.zeros(cout)
+            sd[bn + '.running_var'] = torch.ones(cout)
+            sd[bn + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+        if self.pooling.startswith('gem'):
+            sd['adpool.p'] = torch.ones(1) * self._gemp
+        bound = 1. / math.sqrt(self.trunk_dim)
+        sd['fc.weight'] = (torch.rand(self.out_dim, self.trunk_dim) * 2 - 1) * bound
+        sd['fc.bias'] = (torch.rand(self.out_dim) * 2 - 1) * bound
+        return sd
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._state.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        new = OrderedDict()
+        for k, v in state_dict.items():
+            if k.startswith('module.'):
+                k = k[7:]
+            new[k] = v
+        missing = [k for k in self._state if k not in new and not k.endswith('num_batches_tracked')]
+        unexpected = [k for k in new if k not in self._state]
+        bad = [k for k in new if k in self._state and tuple(new[k].shape) != tuple(self._state[k].shape)]
+        if bad:
+            raise RuntimeError('size mismatch for %s' % ', '.join(bad))
+        if strict and (missing or unexpected):
+            raise RuntimeError('Error(s) in loading state_dict: missing %s, unexpected %s'
+                               % (missing, unexpected))
+        for k, v in new.items():
+            if k in self._state:
+                self._state[k] = v.detach().to('cpu').clone()
+        self._dirty = True
+        return self
+
+    # ---- nn.Module look-alikes -------------------------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('the MI355X engine is inference-only')
+        return self.eval()
+
+    def cuda(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('dirtorch_amd needs a visible MI355X (torch.cuda.is_available() is False)')
+        self.iscuda = True
+        return self
+
+    def cpu(self):
+        raise RuntimeError('dirtorch_amd has no CPU execution path (use the reference or oracle/)')
+
+    def parameters(self):
+        return [v for k, v in self._state.items() if 'running_' not in k and 'num_batches' not in k]
+
+    # ---- engine ----------------------------------------------------------------------------
+    def _build_engine(self):
+        lib = _lib.load()
+        if self._engine is None:
+            d = ModelDesc()
+            d.bottleneck = self.bottleneck
+            for i in range(4):
+                d.layers[i] = self.layers[i]
+            d.out_dim = self.out_dim
+            d.norm_features = int(bool(self.norm_features))
+            d.pooling = POOLING['gem' if self.pooling.startswith('gem') else self.pooling]
+            d.without_fc = int(bool(self.without_fc))
+            d.center_bias = float(self.center_bias)
+            for i in range(3):
+                d.mean[i] = self.rgb_means[i]
+                d.std[i] = self.rgb_stds[i]
+            handle = ctypes.c_void_p()
+            call('dir_engine_create', ctypes.byref(d), torch.cuda.current_device(),
+                 ctypes.byref(handle))
+            self._engine = handle
+        for k, v in self._state.items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            t = v.detach().to(torch.float32).contiguous()
+            shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+            call('dir_engine_set_tensor', self._engine, k.encode(), ctypes.c_void_p(t.data_ptr()),
+                 shape, t.dim())
+        call('dir_engine_finalize', self._engine,
+             _lib.DIR_BF16 if self.compute_dtype == 'bf16' else _lib.DIR_FP16)
+        self._dirty = False
+        self._tuned = set()
+        del lib
+
+    def _workspace(self, B, H, W):
+        need = ctypes.c_size_t()
+        call('dir_workspace_bytes', self._engine, B, H, W, ctypes.byref(need))
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device='cuda')
+        return self._ws
+
+    def _prepare(self, x):
+        if self._dirty or self._engine is None:
+            self._build_engine()
+        if not x.is_cuda:
+            raise RuntimeError('input must live on the GPU (dirtorch_amd has no CPU path)')
+        if x.dtype == torch.uint8:
+            if x.dim() != 4 or x.shape[3] != 3:
+                raise ValueError('uint8 input must be NHWC [B,H,W,3]')
+            B, H, W, _ = x.shape
+            fmt = _lib.DIR_IMG_U8_NHWC
+        else:
+            if x.dim() != 4 or x.shape[1] != 3:
+                raise ValueError('input must be [B,3,H,W]')
+            B, _, H, W = x.shape
+            fmt = _lib.DIR_IMG_F32_NCHW
+            x = x.to(torch.float32)
+        x = x.contiguous()
+        ws = self._workspace(B, H, W)
+        if self.autotune and (B, H, W) not in self._tuned:
+            call('dir_engine_autotune', self._engine, B, H, W, ptr(ws), ws.numel(), stream_ptr())
+            self._tuned.add((B, H, W))
+        return x, B, H, W, fmt, ws
+
+    def forward(self, x):
+        x, B, H, W, fmt, ws = self._prepare(x)
+        D = self.trunk_dim if self.without_fc else self.out_dim
+        out = torch.empty(B, D, dtype=torch.float32, device=x.device)
+        call('dir_forward', self._engine, ptr(x), B, H, W, fmt, ptr(out), ptr(ws), ws.numel(),
+             stream_ptr())
+        if B == 1:
+            out = out.view(D)   # x.squeeze_() of the reference (rmac_resnet.py:64)
+        return out
+
+    __call__ = forward
+
+    def forward_features(self, x):
+        """Trunk feature map, NHWC 16-bit [B,h,w,C] (ResNet.forward, resnet.py:157-174)."""
+        x, B, H, W, fmt, ws = self._prepare(x)
+        h = (((H + 6 - 7) // 2 + 1) - 1) // 2 + 1
+        w = (((W + 6 - 7) // 2 + 1) - 1) // 2 + 1
+        for _ in range(3):
+            h = (h - 1) // 2 + 1
+            w = (w - 1) // 2 + 1
+        dt = torch.bfloat16 if self.compute_dtype == 'bf16' else torch.float16
+        feat = torch.empty(B, h, w, self.trunk_dim, dtype=dt, device=x.device)
+        oh, ow, oc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        call('dir_forward_features', self._engine, ptr(x), B, H, W, fmt, ptr(feat),
+             ctypes.byref(oh), ctypes.byref(ow), ctypes.byref(oc), ptr(ws), ws.numel(), stream_ptr())
+        assert (oh.value, ow.value, oc.value) == (h, w, self.trunk_dim)
+        return feat
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def set_profiling(self, enabled):
+        if self._dirty or self._engine is None:
+            self._build_engine()
+        call('dir_engine_set_profiling', self._engine, int(enabled))
+
+    def get_profile(self, cap=65536):
+        recs = (_lib.ProfRecord * cap)()
+        n = ctypes.c_int()
+        call('dir_engine_get_profile', self._engine, recs, cap, ctypes.byref(n))
+        return [dict(name=r.name.decode(), kernel=r.kernel.decode(), flops=r.flops, bytes=r.bytes,
+                     ms=r.ms) for r in recs[:min(n.value, cap)]]
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                _lib.load().dir_engine_destroy(self._engine)
+                self._engine = None
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return '%s(%s, out_dim=%d, pooling=%s, dtype=%s)' % (
+            type(self).__name__, self.model_name, self.out_dim, self.pooling, self.compute_dtype)
+
+
+def _rmac(name):
+    def factory(backbone=ResNet_RMAC, **kwargs):
+        kwargs.pop('scales', None)   # rmac_resnet.py:75
+        return backbone(name, **kwargs)
+    factory.__name__ = name + '_rmac'
+    return factory
+
+
+resnet18_rmac = _rmac('resnet18')
+resnet50_rmac = _rmac('resnet50')
+resnet101_rmac = _rmac('resnet101')
+resnet152_rmac = _rmac('resnet152')
+
+
+def _not_on_path(name, why):
+    def factory(*args, **kwargs):
+        raise NotImplementedError('%s is registered for name compatibility with dirtorch.nets but '
+                                  'is outside the descriptor hot path (%s)' % (name, why))
+    factory.__name__ = name
+    return factory
+
+
+# classification trunks (resnet.py:205-227) and FPN heads (rmac_resnet_fpn.py): names resolve, as in
+# the reference's model_names, but none of the five released retrieval models uses them.
+resnet18 = _not_on_path('resnet18', 'ImageNet classifier')
+resnet50 = _not_on_path('resnet50', 'ImageNet classifier')
+resnet101 = _not_on_path('resnet101', 'ImageNet classifier')
+resnet152 = _not_on_path('resnet152', 'ImageNet classifier')
+resnet18_fpn_rmac = _not_on_path('resnet18_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
+resnet50_fpn_rmac = _not_on_path('resnet50_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
+resnet101_fpn_rmac = _not_on_path('resnet101_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
+resnet101_fpn0_rmac = _not_on_path('resnet101_fpn0_rmac', 'FPN variant, SURVEY.md §8f N4')
+resnet152_fpn_rmac = _not_on_path('resnet152_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')

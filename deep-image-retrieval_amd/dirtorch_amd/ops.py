@@ -1,0 +1,157 @@
+"""Tensor-level wrappers of the per-op C-ABI entry points (include/dir_engine.h).
+
+torch is used for device memory and the current stream only; every computation below is a HIP
+kernel of libdir_engine.so.  16-bit activations travel as torch.bfloat16 / torch.float16 tensors in
+NHWC layout.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DIR_BF16, DIR_FP16, POOLING, call, ptr, stream_ptr
+
+
+def _dtype_code(t):
+    if t.dtype == torch.bfloat16:
+        return DIR_BF16
+    if t.dtype == torch.float16:
+        return DIR_FP16
+    raise TypeError('16-bit activation tensor expected (bfloat16 or float16), got %s' % t.dtype)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError('device tensor expected')
+        if t is not None and not t.is_contiguous():
+            raise ValueError('contiguous tensor expected')
+
+
+def conv_variant_names():
+    lib = _lib.load()
+    out = []
+    for v in range(lib.dir_conv_variant_count()):
+        buf = ctypes.create_string_buffer(64)
+        call('dir_conv_variant_name', v, buf, 64)
+        out.append(buf.value.decode())
+    return out
+
+
+def pack_conv_weight(w_oihw, dtype=torch.bfloat16):
+    """OIHW fp32 -> [Cout][R][S][Cin] 16-bit (what dir_conv_bn_act expects)."""
+    return w_oihw.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def pack_stem_weight(w_oihw, dtype=torch.bfloat16):
+    """7x7 s2 stem weight [64,3,7,7] -> 4x4 s1 space-to-depth form [64][4][4][16]
+    (tap r = 2R + dy - 1, s = 2S + dx - 1, channel (dy*2+dx)*3 + c); mirrors engine.hip."""
+    O = w_oihw.shape[0]
+    out = torch.zeros(O, 4, 4, 16, dtype=torch.float32, device=w_oihw.device)
+    for R in range(4):
+        for S in range(4):
+            for dy in range(2):
+                for dx in range(2):
+                    r, s = 2 * R + dy - 1, 2 * S + dx - 1
+                    if 0 <= r < 7 and 0 <= s < 7:
+                        c0 = (dy * 2 + dx) * 3
+                        out[:, R, S, c0:c0 + 3] = w_oihw[:, :, r, s]
+    return out.to(dtype)
+
+
+def conv_bn_act(x, w, bias, res=None, stride=1, pad=0, relu=True, out_hw=None, variant=-1,
+                naive=False):
+    """x NHWC [B,H,W,Cin] 16-bit, w [Cout,R,S,Cin] 16-bit, bias fp32 [Cout] -> NHWC [B,OH,OW,Cout]."""
+    _need_cuda(x, w, bias, res)
+    B, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w.shape
+    if Cin2 != Cin:
+        raise ValueError('Cin mismatch')
+    if out_hw is None:
+        OH = (H + 2 * pad - R) // stride + 1
+        OW = (W + 2 * pad - S) // stride + 1
+    else:
+        OH, OW = out_hw
+    y = torch.empty(B, OH, OW, Cout, dtype=x.dtype, device=x.device)
+    args = [ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), B, H, W, Cin, Cout, R, S, stride, pad, OH,
+            OW, int(bool(relu)), _dtype_code(x)]
+    if naive:
+        call('dir_conv_bn_act_naive', *args, stream_ptr())
+    else:
+        call('dir_conv_bn_act', *args, int(variant), stream_ptr())
+    return y
+
+
+def prep_input(img, dtype=torch.bfloat16, mean=None, std=None):
+    """fp32 NCHW (normalised) or uint8 NHWC image batch -> space-to-depth NHWC16 stem input."""
+    _need_cuda(img)
+    if img.dtype == torch.float32:
+        B, C, H, W = img.shape
+        fmt = _lib.DIR_IMG_F32_NCHW
+    elif img.dtype == torch.uint8:
+        B, H, W, C = img.shape
+        fmt = _lib.DIR_IMG_U8_NHWC
+    else:
+        raise TypeError('image must be float32 NCHW or uint8 NHWC')
+    if C != 3:
+        raise ValueError('3-channel image expected')
+    out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 16, dtype=dtype, device=img.device)
+    m = (ctypes.c_float * 3)(*(mean or (0, 0, 0)))
+    s = (ctypes.c_float * 3)(*(std or (1, 1, 1)))
+    call('dir_prep_input', ptr(img), fmt, m, s, ptr(out), B, H, W,
+         DIR_BF16 if dtype == torch.bfloat16 else DIR_FP16, stream_ptr())
+    return out
+
+
+def maxpool_3x3s2(x):
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=x.dtype, device=x.device)
+    call('dir_maxpool_3x3s2', ptr(x), ptr(y), B, H, W, C, _dtype_code(x), stream_ptr())
+    return y
+
+
+def global_pool(x, pooling='gem', p=3.0, eps=1e-6, center_bias=0.0):
+    _need_cuda(x)
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    call('dir_global_pool', ptr(x), ptr(out), B, H, W, C, POOLING[pooling], float(p), float(eps),
+         float(center_bias), _dtype_code(x), stream_ptr())
+    return out
+
+
+def l2norm_rows_(x, eps=1e-12):
+    """In place: x[i] /= max(||x[i]||, eps)."""
+    _need_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise TypeError('2-D float32 tensor expected')
+    call('dir_l2norm_rows', ptr(x), x.shape[0], x.shape[1], float(eps), stream_ptr())
+    return x
+
+
+def gemm_nt(P, Q, qsub=None, bias=None, alpha=None):
+    """out[j][i] = alpha[i] * sum_k P[i][k] * (Q[j][k] - qsub[k]) + bias[i]; fp32, exact MFMA."""
+    _need_cuda(P, Q, qsub, bias, alpha)
+    for t in (P, Q, qsub, bias, alpha):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError('float32 tensors expected')
+    NP, K = P.shape
+    NQ, K2 = Q.shape
+    if K != K2:
+        raise ValueError('inner dimensions differ')
+    out = torch.empty(NQ, NP, dtype=torch.float32, device=P.device)
+    if NP == 0 or NQ == 0:
+        return out
+    call('dir_gemm_nt_f32', ptr(P), K, ptr(Q), K, ptr(out), NP, NP, NQ, K, ptr(qsub), ptr(bias),
+         ptr(alpha), stream_ptr())
+    return out
+
+
+def multiscale_pool(xs, pooling='mean', gemp=3.0):
+    """xs: [S,N,D] fp32 -> [N,D] (mean or signed-power mean); no final L2."""
+    _need_cuda(xs)
+    S, N, D = xs.shape
+    mode = {'mean': 0, 'gem': 1}[pooling]
+    out = torch.empty(N, D, dtype=torch.float32, device=xs.device)
+    call('dir_multiscale_pool', ptr(xs), ptr(out), S, N, D, mode, float(gemp), stream_ptr())
+    return out

@@ -1,0 +1,166 @@
+/*
+ * dir_engine.h — C ABI of the MI355X (gfx950) descriptor-extraction + ranking engine.
+ *
+ * The reference (naver/deep-image-retrieval, "dirtorch") has no FFI of its own: its seam is the
+ * duck-typed Python object returned by dirtorch.nets.create_model (dirtorch/nets/__init__.py:24-64)
+ * plus four free functions of dirtorch/utils/common.py.  Every entry point below names the
+ * reference call it replaces.  The host side (Python, ctypes) lives in
+ * deep-image-retrieval_amd/dirtorch_amd/ and mirrors the reference names one to one.
+ *
+ * Conventions
+ *   - every function returns DIR_OK (0) or a negative dir_status; the message of the last error on
+ *     the calling thread is returned by dir_last_error().  No C++ exception crosses this boundary.
+ *   - all tensor pointers are DEVICE pointers owned by the caller unless the name says host_;
+ *     `stream` is a hipStream_t passed as void* (NULL = the default stream).  Nothing here
+ *     synchronises the device except dir_engine_finalize and the profiling getters.
+ *   - activations are NHWC, 16-bit (bf16 or fp16, chosen at finalize); accumulation is fp32.
+ *   - the engine owns only its packed weights; the caller owns images, descriptors and workspace.
+ *   - a handle is not re-entrant: one handle per device, one calling thread at a time
+ *     (the reference calls net(x) from one thread, dirtorch/test_dir.py:67-81).
+ */
+#ifndef DIR_ENGINE_H
+#define DIR_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dir_status {
+    DIR_OK = 0,
+    DIR_ERR_INVALID = -1,     /* bad argument / unsupported configuration            */
+    DIR_ERR_STATE = -2,       /* call out of order (e.g. forward before finalize)    */
+    DIR_ERR_MISSING = -3,     /* a state-dict tensor was never supplied              */
+    DIR_ERR_WORKSPACE = -4,   /* workspace too small                                 */
+    DIR_ERR_HIP = -5,         /* a HIP runtime call failed                           */
+    DIR_ERR_NOMEM = -6
+} dir_status;
+
+typedef enum dir_dtype {
+    DIR_BF16 = 0,             /* bf16 activations/weights, fp32 accumulate (default) */
+    DIR_FP16 = 1              /* fp16 activations/weights, fp32 accumulate           */
+} dir_dtype;
+
+typedef enum dir_img_format {
+    DIR_IMG_F32_NCHW = 0,     /* what the reference feeds net(x): normalised fp32 NCHW
+                                 (dirtorch/utils/transforms.py:617-623 ToTensor+Normalize) */
+    DIR_IMG_U8_NHWC = 1       /* raw uint8 HWC pixels; (x/255-mean)/std is fused on device  */
+} dir_img_format;
+
+typedef enum dir_pooling {    /* dirtorch/nets/rmac_resnet.py:24-31                         */
+    DIR_POOL_GEM = 0,
+    DIR_POOL_MAX = 1,
+    DIR_POOL_AVG = 2
+} dir_pooling;
+
+/* Mirrors the keyword arguments of ResNet_RMAC.__init__ (dirtorch/nets/rmac_resnet.py:15-17)
+ * and the layer counts of the resnet{18,50,101,152}_rmac factories (:74-88). */
+typedef struct dir_model_desc {
+    int   bottleneck;         /* 1 = Bottleneck blocks (R50/101/152), 0 = BasicBlock (R18)  */
+    int   layers[4];          /* blocks per stage, e.g. {3,4,23,3}                          */
+    int   out_dim;            /* FC output size (2048)                                      */
+    int   norm_features;      /* L2 over channels before the FC                             */
+    int   pooling;            /* dir_pooling                                                */
+    int   without_fc;         /* skip the FC                                                */
+    float center_bias;        /* >0: bilinear 4x4 centre mask before pooling (:52-56)       */
+    float mean[3];            /* used by DIR_IMG_U8_NHWC only                               */
+    float std[3];
+} dir_model_desc;
+
+typedef struct dir_engine dir_engine;
+
+const char* dir_last_error(void);
+/* "dir_engine <version> gfx950" — lets the host check it loaded the library it expects. */
+const char* dir_version(void);
+
+/* ---- model life cycle: replaces nets.create_model + net.load_state_dict + net.cuda() ------- */
+/* dirtorch/nets/__init__.py:24-64, dirtorch/test_dir.py:183-191 */
+int dir_engine_create(const dir_model_desc* desc, int device, dir_engine** out);
+int dir_engine_destroy(dir_engine* e);
+/* One call per state-dict entry, reference key names (conv1.weight, bn1.running_mean,
+ * layer3.7.conv2.weight, layer2.0.downsample.1.bias, adpool.p, fc.weight, fc.bias, …), host fp32,
+ * PyTorch layouts (OIHW for convs).  num_batches_tracked entries are accepted and ignored. */
+int dir_engine_set_tensor(dir_engine* e, const char* ref_key, const float* host_data,
+                          const int64_t* shape, int ndim);
+/* Folds eval-mode BatchNorm (eps 1e-5, dirtorch/nets/backbones/resnet.py:117) into the conv
+ * weights, repacks OIHW -> [Cout][R][S][Cin] 16-bit, uploads.  DIR_ERR_MISSING names the key. */
+int dir_engine_finalize(dir_engine* e, int dtype /* dir_dtype */);
+int dir_engine_out_dim(const dir_engine* e, int* out_dim);
+
+/* ---- forward: replaces ResNet_RMAC.forward (dirtorch/nets/rmac_resnet.py:39-69) ------------ */
+int dir_workspace_bytes(const dir_engine* e, int B, int H, int W, size_t* bytes);
+/* desc_out: B x D fp32, unit L2 norm.  (The reference's squeeze_ to [D] at B == 1 is a host-side
+ * view, rmac_resnet.py:64.)  img: B x 3 x H x W fp32 or B x H x W x 3 uint8, per img_format. */
+int dir_forward(dir_engine* e, const void* img, int B, int H, int W, int img_format,
+                float* desc_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Same, but also returns the trunk feature map (NHWC 16-bit, B x h x w x C) for block-level
+ * parity tests against ResNet.forward (dirtorch/nets/backbones/resnet.py:157-174). */
+int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, int img_format,
+                         void* feat_out, int* h, int* w, int* c,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Tile-variant selection for the implicit-GEMM convolutions: run every admissible variant on each
+ * layer shape of a B x H x W forward and keep the fastest (synchronises).  Optional. */
+int dir_engine_autotune(dir_engine* e, int B, int H, int W, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ---- per-launch profile (HIP events on the launch stream) ---------------------------------- */
+typedef struct dir_prof_record {
+    char     name[48];        /* layer name, e.g. "layer3.4.conv2"                          */
+    char     kernel[48];      /* kernel family + variant, e.g. "conv_igemm<128x128>"        */
+    double   flops;           /* algorithmic FLOPs of this launch (2*MACs)                  */
+    double   bytes;           /* algorithmic bytes (compulsory in + out + weights)          */
+    float    ms;              /* event-measured duration                                    */
+} dir_prof_record;
+/* enabled: 0 off, 1 on, n > 1 on with n event pairs pre-created (keeps event creation out of
+ * a timed region). */
+int dir_engine_set_profiling(dir_engine* e, int enabled);
+/* Synchronises; copies up to `cap` records of the launches made since the last call. */
+int dir_engine_get_profile(dir_engine* e, dir_prof_record* out, int cap, int* n);
+
+/* ---- per-op entry points (op-level parity tests) ----------------------- */
+/* K1/K2/K4-K7: conv + folded BN bias (+ residual) (+ ReLU); x NHWC [B,H,W,Cin] 16-bit,
+ * w [Cout][R][S][Cin] 16-bit, bias fp32[Cout], res/y NHWC [B,OH,OW,Cout].
+ * variant < 0: heuristic choice; otherwise index into dir_conv_variant_count(). Cin % 64 == 0,
+ * or Cin == 16 with R == S == 4 (the space-to-depth stem). */
+int dir_conv_variant_count(void);
+int dir_conv_variant_name(int variant, char* buf, int cap);
+int dir_conv_bn_act(const void* x, const void* w, const float* bias, const void* res, void* y,
+                    int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                    int pad, int OH, int OW, int relu, int dtype, int variant, void* stream);
+/* Slow, obviously-correct direct convolution with the same contract (device-side checker). */
+int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res,
+                          void* y, int B, int H, int W, int Cin, int Cout, int R, int S,
+                          int stride, int pad, int OH, int OW, int relu, int dtype, void* stream);
+/* Image -> space-to-depth stem input [B, ceil(H/2), ceil(W/2), 16] 16-bit (12 used channels). */
+int dir_prep_input(const void* img, int img_format, const float* mean3, const float* std3,
+                   void* out, int B, int H, int W, int dtype, void* stream);
+/* K3: MaxPool2d(3, stride 2, pad 1) on NHWC (dirtorch/nets/backbones/resnet.py:119). */
+int dir_maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* K8: global pooling over H*W of NHWC x -> fp32 [B,C] (dirtorch/nets/layers/pooling.py:38-40);
+ * pooling = dir_pooling, p = GeM exponent (runtime scalar), eps = 1e-6 clamp;
+ * center_bias > 0 applies the bilinear mask of rmac_resnet.py:52-56 first. */
+int dir_global_pool(const void* x, float* out, int B, int H, int W, int C, int pooling, float p,
+                    float eps, float center_bias, int dtype, void* stream);
+/* L2-normalise each row in place: x / max(||x||, eps) (F.normalize, rmac_resnet.py:7-9). */
+int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream);
+/* K9/K11/K12: out[j][i] = alpha_i * (sum_k P[i][k] * (Q[j][k] - qsub[k])) + bias[i]
+ *   P: [NP,K] fp32 (ldp), Q: [NQ,K] fp32 (ldq), out: [NQ,NP] fp32 (ldo); qsub/bias/alpha may be
+ *   NULL.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Used as
+ *     FC          : P = fc.weight, Q = pooled features, bias = fc.bias   (rmac_resnet.py:66)
+ *     PCA whiten  : P = components_[:v], Q = X, qsub = mean_, alpha = 1/(m*var^p) (common.py:221-232)
+ *     similarity  : P = database descriptors, Q = queries -> scores[Q][N]       (common.py:30-38) */
+int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo,
+                    int NP, int NQ, int K, const float* qsub, const float* bias,
+                    const float* alpha, void* stream);
+/* K10: multi-scale pooling of S descriptor sets [S][N][D] -> [N][D] (common.py:41-55):
+ * mode 0 = mean, 1 = signed-power ("gem") mean with exponent gemp; no final L2 (caller does it). */
+int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIR_ENGINE_H */

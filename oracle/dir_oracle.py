@@ -1,0 +1,322 @@
+"""CPU oracle for the descriptor-extraction + ranking path of naver/deep-image-retrieval.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module, and only as the checker - the product (deep-image-retrieval_amd/) never does.
+
+It restates, function by function, the arithmetic of the reference's hot path in plain fp32
+PyTorch-CPU / NumPy, with no dependency on /root/reference at run time:
+
+    resnet_features      dirtorch/nets/backbones/resnet.py:157-174 (ResNet.forward),
+                         :67-87 (Bottleneck.forward), :29-44 (BasicBlock.forward), :134-141
+    rmac_forward         dirtorch/nets/rmac_resnet.py:39-69 (ResNet_RMAC.forward)
+    gem_pool             dirtorch/nets/layers/pooling.py:38-40
+    pool                 dirtorch/utils/common.py:41-55
+    whiten_features      dirtorch/utils/common.py:221-239
+    matmul               dirtorch/utils/common.py:30-38
+    compute_average_precision   dirtorch/utils/evaluation.py:46-82
+    eval_query_AP        dirtorch/datasets/generic.py:189-224 (+ get_relevants/get_junk :150-170)
+
+Pinning: the reference ships no tests and no golden vectors, so the pins are outputs
+of the reference itself, imported in the build container by tests/golden/make_golden.py and
+committed under tests/golden/*.npz; tests/test_oracle_golden.py checks this module against them.
+The third-party arithmetic underneath (PyTorch conv/BN/linear kernels, sklearn PCA attributes) is
+"parity unpinned" beyond that: the reference pins no version or vector for it.
+
+`quant=` emulates the engine's 16-bit storage points (weights after BN folding, every activation
+tensor written to HBM) with fp32 accumulation, so kernel bugs can be told from precision drift.
+"""
+import hashlib
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ARCH = {
+    'resnet18': (False, [2, 2, 2, 2]),
+    'resnet50': (True, [3, 4, 6, 3]),
+    'resnet101': (True, [3, 4, 23, 3]),
+    'resnet152': (True, [3, 8, 36, 3]),
+}
+BN_EPS = 1e-5  # nn.BatchNorm2d default, resnet.py:117
+
+
+# ---- deterministic synthetic checkpoints ----------------------------------------------------
+def conv_specs(arch):
+    """[(weight key, bn prefix, cout, cin, k, stride)] in the reference's state-dict order."""
+    bottleneck, layers = ARCH[arch]
+    exp = 4 if bottleneck else 1
+    specs = [('conv1.weight', 'bn1', 64, 3, 7, 2)]
+    inplanes = 64
+    for s, planes in enumerate((64, 128, 256, 512)):
+        for j in range(layers[s]):
+            pre = 'layer%d.%d' % (s + 1, j)
+            stride = 2 if (j == 0 and s > 0) else 1
+            if bottleneck:
+                specs += [(pre + '.conv1.weight', pre + '.bn1', planes, inplanes, 1, 1),
+                          (pre + '.conv2.weight', pre + '.bn2', planes, planes, 3, stride),
+                          (pre + '.conv3.weight', pre + '.bn3', planes * 4, planes, 1, 1)]
+            else:
+                specs += [(pre + '.conv1.weight', pre + '.bn1', planes, inplanes, 3, stride),
+                          (pre + '.conv2.weight', pre + '.bn2', planes, planes, 3, 1)]
+            if j == 0 and (stride != 1 or inplanes != planes * exp):
+                specs.append((pre + '.downsample.0.weight', pre + '.downsample.1', planes * exp,
+                              inplanes, 1, stride))
+            inplanes = planes * exp
+    return specs, inplanes
+
+
+def _rng(seed, key):
+    h = hashlib.sha256(('%d:%s' % (seed, key)).encode()).digest()
+    return np.random.RandomState(int.from_bytes(h[:4], 'little'))
+
+
+def synth_state_dict(arch, seed=0, out_dim=2048, gemp=2.7, pooling='gem'):
+    """Deterministic per-key weights: identical wherever they are generated (golden script, tests,
+    GPU box).  He-normal convs as reset_weights (resnet.py:92-99) but NON-trivial BatchNorm
+    statistics, a non-integer GeM exponent, and a damped last BN per block so that activations
+    stay O(1..100) through 33 residual blocks (fp16-safe)."""
+    specs, feat = conv_specs(arch)
+    sd = OrderedDict()
+    for wkey, bn, cout, cin, k, _ in specs:
+        n = k * k * cout
+        sd[wkey] = torch.from_numpy(
+            (_rng(seed, wkey).standard_normal((cout, cin, k, k)) * math.sqrt(2. / n)).astype(np.float32))
+        r = _rng(seed, bn)
+        last = bn.endswith('bn3') or (not ARCH[arch][0] and bn.endswith('bn2')) or 'downsample' in bn
+        lo, hi = (0.25, 0.5) if last else (0.6, 1.2)
+        sd[bn + '.weight'] = torch.from_numpy(r.uniform(lo, hi, cout).astype(np.float32))
+        sd[bn + '.bias'] = torch.from_numpy((r.standard_normal(cout) * 0.1).astype(np.float32))
+        sd[bn + '.running_mean'] = torch.from_numpy((r.standard_normal(cout) * 0.1).astype(np.float32))
+        sd[bn + '.running_var'] = torch.from_numpy(r.uniform(0.6, 1.6, cout).astype(np.float32))
+        sd[bn + '.num_batches_tracked'] = torch.tensor(1, dtype=torch.long)
+    if pooling.startswith('gem'):
+        sd['adpool.p'] = torch.ones(1) * gemp
+    r = _rng(seed, 'fc')
+    bound = 1. / math.sqrt(feat)
+    sd['fc.weight'] = torch.from_numpy(r.uniform(-bound, bound, (out_dim, feat)).astype(np.float32))
+    sd['fc.bias'] = torch.from_numpy(r.uniform(-bound, bound, out_dim).astype(np.float32))
+    return sd
+
+
+def synth_images(seed, B, H, W):
+    """Normalised fp32 NCHW images with planted low-frequency structure (not white noise)."""
+    r = _rng(seed, 'img%dx%dx%d' % (B, H, W))
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing='ij')
+    imgs = np.empty((B, 3, H, W), np.float32)
+    for b in range(B):
+        for c in range(3):
+            f = r.uniform(1, 6, 2)
+            ph = r.uniform(0, 6.28, 2)
+            imgs[b, c] = (np.sin(f[0] * 6.28 * yy + ph[0]) * np.cos(f[1] * 6.28 * xx + ph[1])
+                          + 0.35 * r.standard_normal((H, W)))
+    return torch.from_numpy(imgs)
+
+
+# ---- 16-bit emulation ---------------------------------------------------------------------------
+def _q(t, quant):
+    if quant is None:
+        return t
+    dt = {'bf16': torch.bfloat16, 'fp16': torch.float16}[quant]
+    return t.to(dt).to(torch.float32)
+
+
+def _fold(sd, wkey, bn, quant):
+    """Conv weight/bias with eval-mode BatchNorm folded in (what the engine packs)."""
+    w = sd[wkey].float()
+    scale = sd[bn + '.weight'].float() / torch.sqrt(sd[bn + '.running_var'].float() + BN_EPS)
+    bias = sd[bn + '.bias'].float() - sd[bn + '.running_mean'].float() * scale
+    return _q(w * scale.view(-1, 1, 1, 1), quant), bias
+
+
+def _conv_bn(sd, x, wkey, bn, stride, pad, quant):
+    if quant is None:
+        # the reference's own op order: conv, then BatchNorm2d in eval mode
+        y = F.conv2d(x, sd[wkey].float(), None, stride, pad)
+        return F.batch_norm(y, sd[bn + '.running_mean'].float(), sd[bn + '.running_var'].float(),
+                            sd[bn + '.weight'].float(), sd[bn + '.bias'].float(), False, 0.0, BN_EPS)
+    w, b = _fold(sd, wkey, bn, quant)
+    return F.conv2d(x, w, b, stride, pad)
+
+
+# ---- trunk ----------------------------------------------------------------------------------------
+def resnet_features(sd, arch, x, quant=None):
+    """ResNet.forward up to layer4 (fc_out == 0 for *_rmac): [B,3,H,W] -> [B,C,h,w] fp32."""
+    bottleneck, layers = ARCH[arch]
+    x = _q(x.float(), quant)
+    x = _q(F.relu(_conv_bn(sd, x, 'conv1.weight', 'bn1', 2, 3, quant)), quant)
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    inplanes = 64
+    exp = 4 if bottleneck else 1
+    for s, planes in enumerate((64, 128, 256, 512)):
+        for j in range(layers[s]):
+            pre = 'layer%d.%d' % (s + 1, j)
+            stride = 2 if (j == 0 and s > 0) else 1
+            residual = x
+            if bottleneck:
+                out = _q(F.relu(_conv_bn(sd, x, pre + '.conv1.weight', pre + '.bn1', 1, 0, quant)), quant)
+                out = _q(F.relu(_conv_bn(sd, out, pre + '.conv2.weight', pre + '.bn2', stride, 1, quant)), quant)
+                out = _conv_bn(sd, out, pre + '.conv3.weight', pre + '.bn3', 1, 0, quant)
+            else:
+                out = _q(F.relu(_conv_bn(sd, x, pre + '.conv1.weight', pre + '.bn1', stride, 1, quant)), quant)
+                out = _conv_bn(sd, out, pre + '.conv2.weight', pre + '.bn2', 1, 1, quant)
+            if j == 0 and (stride != 1 or inplanes != planes * exp):
+                residual = _q(_conv_bn(sd, x, pre + '.downsample.0.weight', pre + '.downsample.1',
+                                       stride, 0, quant), quant)
+            x = _q(F.relu(out + residual), quant)
+            inplanes = planes * exp
+    return x
+
+
+def gem_pool(x, p, eps=1e-6):
+    """GeneralizedMeanPooling.forward with output_size 1: [B,C,h,w] -> [B,C,1,1]."""
+    x = x.clamp(min=eps).pow(p)
+    return F.adaptive_avg_pool2d(x, 1).pow(1. / p)
+
+
+def center_bias_mask(b, size):
+    bias = 1 + torch.tensor([[[[0, 0, 0, 0], [0, b, b, 0], [0, b, b, 0], [0, 0, 0, 0]]]], dtype=torch.float32)
+    return F.interpolate(bias, size=size, mode='bilinear', align_corners=True)
+
+
+def rmac_head(sd, feat, pooling='gem', norm_features=False, center_bias=0, without_fc=False):
+    """rmac_resnet.py:52-68 from the trunk output on: returns [B,D], or [D] when B == 1."""
+    x = feat
+    if center_bias > 0:
+        x = x * center_bias_mask(center_bias, x.shape[-2:])
+    if pooling == 'max':
+        x = F.adaptive_max_pool2d(x, 1)
+    elif pooling == 'avg':
+        x = F.adaptive_avg_pool2d(x, 1)
+    elif pooling.startswith('gem'):
+        x = gem_pool(x, sd['adpool.p'].float())
+    else:
+        raise ValueError(pooling)
+    if norm_features:
+        x = F.normalize(x, p=2, dim=1)
+    x = x.squeeze()
+    if x.dim() == 0:
+        x = x.view(1)
+    if not without_fc:
+        x = F.linear(x, sd['fc.weight'].float(), sd['fc.bias'].float())
+    return F.normalize(x, p=2, dim=-1)
+
+
+def rmac_forward(sd, arch, x, pooling='gem', norm_features=False, center_bias=0, without_fc=False,
+                 quant=None):
+    with torch.no_grad():
+        feat = resnet_features(sd, arch, x, quant)
+        return rmac_head(sd, feat, pooling, norm_features, center_bias, without_fc)
+
+
+# ---- post-processing --------------------------------------------------------------------------------
+def pool(x, pooling='mean', gemp=3):
+    """common.pool: list of [N,D] tensors -> [N,D] (identity for a single scale)."""
+    if len(x) == 1:
+        return x[0]
+    x = torch.stack(x, dim=0)
+    if pooling == 'mean':
+        return torch.mean(x, dim=0)
+    elif pooling == 'gem':
+        def sympow(x, p, eps=1e-6):
+            s = torch.sign(x)
+            return (x * s).clamp(min=eps).pow(p) * s
+        x = sympow(x, gemp)
+        x = torch.mean(x, dim=0)
+        return sympow(x, 1 / gemp)
+    raise ValueError("Bad pooling mode: " + str(pooling))
+
+
+class PCAParams(object):
+    """The four attributes common.transform reads from an sklearn PCA (common.py:224-228)."""
+
+    def __init__(self, mean_, components_, explained_variance_, whiten=True):
+        self.mean_ = mean_
+        self.components_ = components_
+        self.explained_variance_ = explained_variance_
+        self.whiten = whiten
+
+
+def fit_pca(X, whiten=True):
+    """Exact PCA by SVD on centred data (what sklearn's full solver computes, up to sign)."""
+    X = np.asarray(X, dtype=np.float64)
+    mean = X.mean(axis=0)
+    U, S, Vt = np.linalg.svd(X - mean, full_matrices=False)
+    var = (S ** 2) / (X.shape[0] - 1)
+    return PCAParams(mean.astype(np.float32), Vt.astype(np.float32), var.astype(np.float32), whiten)
+
+
+def whiten_features(X, pca, l2norm=True, whitenp=0.5, whitenv=None, whitenm=1.0):
+    """common.transform + whiten_features (use_sklearn=True branch)."""
+    if pca.mean_ is not None:
+        X = X - pca.mean_
+    Xt = np.dot(X, pca.components_[:whitenv].T)
+    if pca.whiten:
+        Xt = Xt / (whitenm * np.power(pca.explained_variance_[:whitenv], whitenp))
+    if l2norm:
+        Xt = Xt / np.expand_dims(np.linalg.norm(Xt, axis=1), axis=1)
+    return Xt
+
+
+def matmul(A, B):
+    """Q x N similarity scores as fp32 NumPy (common.matmul)."""
+    return np.dot(np.asarray(A), np.asarray(B).T)
+
+
+# ---- ranking / AP (revisited Oxford/Paris protocol) ---------------------------------------------------
+def compute_average_precision(positive_ranks):
+    """Trapezoidal AP over sorted zero-based ranks of the positives (evaluation.py:46-82)."""
+    ap = 0.0
+    n = len(positive_ranks)
+    if not n:
+        return ap
+    step = 1.0 / n
+    for i, rank in enumerate(positive_ranks):
+        left = 1.0 if not rank else i / rank
+        right = (i + 1) / (rank + 1)
+        ap += (left + right) * step / 2
+    return ap
+
+
+def eval_query_AP(scores, easy, hard, junk):
+    """{'easy','medium','hard'} AP of one query from its score row (generic.py:209-224).
+    easy/hard/junk are index lists as in the revisitop gnd pickle; ties rank by descending index
+    (np.argsort(...)[::-1])."""
+    N = scores.shape[0]
+    d = {}
+    for mode in ('easy', 'medium', 'hard'):
+        if mode == 'easy':
+            rel, jk = list(easy), list(junk) + list(hard)
+        elif mode == 'medium':
+            rel, jk = list(easy) + list(hard), list(junk)
+        else:
+            rel, jk = list(hard), list(junk) + list(easy)
+        gt = -np.ones(N, dtype=np.int8)
+        gt[rel] = 1
+        gt[jk] = 0
+        keep = gt != 0
+        if np.sum(gt[keep] > 0) == 0:
+            d[mode] = -1
+        else:
+            gt2, s2 = gt[keep], scores[keep]
+            gt_sorted = gt2[np.argsort(s2)[::-1]]
+            d[mode] = compute_average_precision(np.where(gt_sorted == 1)[0])
+    return d
+
+
+def mean_ap(scores, gnd):
+    """mAP-easy/medium/hard over all queries; gnd = list of {'easy','hard','junk'} dicts
+    (the aggregation of dirtorch/test_dir.py:153-167: queries with AP -1 are skipped)."""
+    aps = [eval_query_AP(scores[q], g['easy'], g['hard'], g['junk']) for q, g in enumerate(gnd)]
+    res = {}
+    for mode in ('easy', 'medium', 'hard'):
+        v = [a[mode] for a in aps if a[mode] >= 0]
+        res['mAP-' + mode] = float(np.mean(v)) if v else float('nan')
+    return res
+
+
+def cosine(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1, np.asarray(a).shape[-1])
+    b = np.asarray(b, dtype=np.float64).reshape(-1, np.asarray(b).shape[-1])
+    return np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))

@@ -1,0 +1,137 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py
+
+What is pinned (reference file:line):
+    descriptors      dirtorch.nets.create_model(...)(x)      nets/__init__.py:24, rmac_resnet.py:39-69
+    trunk features   ResNet.forward                          backbones/resnet.py:157-174
+    pool             dirtorch.utils.common.pool              utils/common.py:41-55
+    whiten_features  dirtorch.utils.common.whiten_features   utils/common.py:221-239  (sklearn PCA)
+    matmul           dirtorch.utils.common.matmul            utils/common.py:30-38
+    AP               compute_average_precision               utils/evaluation.py:46-82
+    eval_query_AP    ImageListRelevants.eval_query_AP        datasets/generic.py:196-224
+
+Weights and images come from oracle/dir_oracle.py's deterministic generators (synth_state_dict,
+synth_images), so the fixtures hold only the reference's OUTPUTS (a few hundred KB).
+"""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+os.environ.setdefault('DB_ROOT', tempfile.gettempdir())
+sys.path.insert(0, '/root/reference')
+
+import dir_oracle as O  # noqa: E402
+
+import dirtorch.nets as ref_nets  # noqa: E402
+from dirtorch.utils import common as ref_common  # noqa: E402
+from dirtorch.utils.evaluation import compute_average_precision as ref_ap  # noqa: E402
+from dirtorch.datasets.generic import ImageListRelevants  # noqa: E402
+
+torch.set_num_threads(8)
+
+# (tag, arch, model options, gemp in checkpoint, B, H, W)
+MODEL_CASES = [
+    ('r18_gem', 'resnet18', dict(), 2.7, 2, 96, 80),
+    ('r50_gem', 'resnet50', dict(), 2.7, 2, 97, 75),          # odd H and W
+    ('r50_gem_b1', 'resnet50', dict(), 3.0, 1, 64, 64),       # B == 1 -> shape (D,)
+    ('r50_max_norm', 'resnet50', dict(pooling='max', norm_features=True), None, 2, 64, 96),
+    ('r50_avg_cb', 'resnet50', dict(pooling='avg', center_bias=0.5, out_dim=512), None, 2, 64, 64),
+    ('r50_nofc', 'resnet50', dict(without_fc=True), 2.2, 2, 64, 64),
+    ('r101_gem', 'resnet101', dict(), 2.7, 1, 128, 96),
+]
+
+
+def model_goldens():
+    out = {}
+    for tag, arch, opts, gemp, B, H, W in MODEL_CASES:
+        pooling = opts.get('pooling', 'gem')
+        sd = O.synth_state_dict(arch, seed=7, out_dim=opts.get('out_dim', 2048),
+                                gemp=gemp if gemp else 3.0, pooling=pooling)
+        net = ref_nets.create_model(arch + '_rmac', pretrained='', **opts)
+        net.load_state_dict(sd)
+        net.eval()
+        x = O.synth_images(11, B, H, W)
+        with torch.no_grad():
+            feat = ref_nets.rmac_resnet.ResNet.forward(net, x)
+            desc = net(x.clone())
+        out[tag + '.desc'] = desc.numpy()
+        # a thin slice of the trunk output is enough to pin ResNet.forward (the full map is MBs)
+        out[tag + '.feat_slice'] = feat[:, ::64, :, :].numpy()
+        out[tag + '.feat_shape'] = np.array(feat.shape)
+        print(tag, 'desc', tuple(desc.shape), 'feat', tuple(feat.shape))
+    np.savez_compressed(os.path.join(HERE, 'model_goldens.npz'), **out)
+
+
+def postproc_goldens():
+    from sklearn.decomposition import PCA
+    r = np.random.RandomState(3)
+    out = {}
+    # multi-scale pooling
+    xs = [torch.from_numpy(r.standard_normal((5, 64)).astype(np.float32)) for _ in range(3)]
+    xs[1][0, :4] = 0.0  # exercises sign(0) = 0
+    out['pool.in'] = torch.stack(xs).numpy()
+    out['pool.mean'] = ref_common.pool(xs, 'mean').numpy()
+    out['pool.gem3'] = ref_common.pool(xs, 'gem', 3).numpy()
+    out['pool.gem2.5'] = ref_common.pool(xs, 'gem', 2.5).numpy()
+    # PCA whitening with a real sklearn object
+    base = r.standard_normal((300, 96)).astype(np.float32) @ r.standard_normal((96, 96)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    pca = PCA(whiten=True)
+    pca.fit(base)
+    X = base[:40] + 0.01 * r.standard_normal((40, 96)).astype(np.float32)
+    out['pca.mean'] = pca.mean_
+    out['pca.components'] = pca.components_
+    out['pca.var'] = pca.explained_variance_
+    out['whiten.in'] = X
+    out['whiten.p0.5'] = ref_common.whiten_features(X, pca, whitenp=0.5)
+    out['whiten.p0.25_v32_m2'] = ref_common.whiten_features(X, pca, whitenp=0.25, whitenv=32, whitenm=2.0)
+    out['whiten.nol2'] = ref_common.whiten_features(X, pca, l2norm=False, whitenp=0.5)
+    # similarity
+    A = r.standard_normal((7, 96)).astype(np.float32)
+    Bm = r.standard_normal((33, 96)).astype(np.float32)
+    out['matmul.A'] = A
+    out['matmul.B'] = Bm
+    out['matmul.np'] = ref_common.matmul(A, Bm)
+    out['matmul.torch'] = ref_common.matmul(torch.from_numpy(A), torch.from_numpy(Bm))
+    # AP known answers
+    ranks = [[0, 1, 2], [1, 3], [0], [], [2, 5, 9], [0, 7, 8, 30]]
+    out['ap.values'] = np.array([ref_ap(np.array(k)) for k in ranks])
+    out['ap.ranks'] = np.array([','.join(map(str, k)) for k in ranks])
+    # revisitop-protocol eval_query_AP on a synthetic ground truth
+    N, Q = 200, 6
+    gnd = []
+    for q in range(Q):
+        perm = r.permutation(N)
+        gnd.append({'bbx': [0, 0, 10, 10], 'easy': sorted(perm[:5].tolist()),
+                    'hard': sorted(perm[5:12].tolist()), 'junk': sorted(perm[12:20].tolist())})
+    gnd[4]['easy'] = []   # a query without easy positives -> AP -1 in 'easy' mode
+    gt = {'imlist': ['im%04d' % i for i in range(N)], 'qimlist': ['q%d' % i for i in range(Q)], 'gnd': gnd}
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, 'gnd_synth.pkl')
+        with open(f, 'wb') as fh:
+            pickle.dump(gt, fh)
+        db = ImageListRelevants(f, root=d)
+    scores = r.standard_normal((Q, N)).astype(np.float32)
+    scores[2, 10] = scores[2, 11]  # a tie
+    aps = [db.eval_query_AP(q, scores[q]) for q in range(Q)]
+    out['evalap.scores'] = scores
+    out['evalap.gnd'] = np.array([pickle.dumps(gnd)], dtype=object)
+    for mode in ('easy', 'medium', 'hard'):
+        out['evalap.' + mode] = np.array([a[mode] for a in aps], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'postproc_goldens.npz'), **out)
+    print('postproc goldens written')
+
+
+if __name__ == '__main__':
+    model_goldens()
+    postproc_goldens()

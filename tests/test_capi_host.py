@@ -1,0 +1,89 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/dir_engine.h,
+and the host-side mirror of dirtorch.nets behaves like the reference's factory.  No compute calls."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'dir_engine.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dir_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dirtorch_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), 'missing export ' + s
+        assert s in _lib.SIGNATURES, 'no ctypes signature for ' + s
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.dir_version().decode().endswith('gfx950')
+    assert lib.dir_conv_variant_count() >= 4
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from dirtorch_amd import _lib
+    lib = _lib.load()
+    import ctypes
+    rc = lib.dir_engine_set_tensor(None, b'x', None, None, 0)
+    assert rc == -1 and b'null' in lib.dir_last_error()
+    n = ctypes.c_int()
+    assert lib.dir_engine_out_dim(None, ctypes.byref(n)) == -1
+    with pytest.raises(_lib.DirError):
+        _lib.call('dir_conv_variant_name', 9999, ctypes.create_string_buffer(8), 8)
+
+
+def test_model_names_match_reference():
+    from dirtorch_amd import nets
+    expected = {'resnet18', 'resnet50', 'resnet101', 'resnet152',
+                'resnet18_rmac', 'resnet50_rmac', 'resnet101_rmac', 'resnet152_rmac',
+                'resnet18_fpn_rmac', 'resnet50_fpn_rmac', 'resnet101_fpn_rmac',
+                'resnet101_fpn0_rmac', 'resnet152_fpn_rmac'}
+    assert nets.model_names == expected        # dirtorch/nets/__init__.py:18-21 [probed: 13 names]
+    with pytest.raises(NameError):
+        nets.create_model('resnet34_rmac')
+    with pytest.raises(ValueError):
+        nets.create_model('resnet50_rmac', pooling='median')   # rmac_resnet.py:31
+    with pytest.raises(NotImplementedError):
+        nets.create_model('resnet50_fpn_rmac')
+
+
+def test_state_dict_keys_and_shapes_match_reference_layout():
+    import dir_oracle as O
+    from dirtorch_amd import nets
+    for arch, nkeys in (('resnet50', 321), ('resnet101', 627)):   # SURVEY.md §5 [probed]
+        net = nets.create_model(arch + '_rmac', scales=[1])       # 'scales' silently dropped
+        sd = net.state_dict()
+        assert len(sd) == nkeys
+        ref = O.synth_state_dict(arch, seed=0)
+        assert list(sd.keys()) == list(ref.keys())
+        for k in sd:
+            assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+        assert net.preprocess == dict(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], input_size=224)
+        net.load_state_dict({'module.' + k: v for k, v in ref.items()})   # DataParallel prefix
+        assert torch.equal(net.state_dict()['adpool.p'], ref['adpool.p'])
+        with pytest.raises(RuntimeError):
+            net.load_state_dict({k: v for k, v in list(ref.items())[:10]})
+        with pytest.raises(RuntimeError):
+            bad = dict(ref)
+            bad['fc.bias'] = torch.zeros(7)
+            net.load_state_dict(bad)
+
+
+def test_no_cpu_execution_path():
+    from dirtorch_amd import nets
+    net = nets.create_model('resnet18_rmac')
+    with pytest.raises(RuntimeError):
+        net.cpu()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            net.cuda()
+        with pytest.raises((RuntimeError, Exception)):
+            net(torch.zeros(1, 3, 64, 64))

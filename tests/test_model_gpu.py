@@ -1,0 +1,143 @@
+"""Block- and model-level parity on the MI355X.
+
+  * engine descriptors vs the REFERENCE's own outputs (tests/golden/model_goldens.npz):
+    cosine >= 1 - 1e-4 (the north-star tolerance), same shapes incl. the (D,) squeeze at B == 1;
+  * engine trunk features vs the oracle with the engine's 16-bit storage points emulated
+    (tight: only summation order differs);
+  * a BASELINE-size forward (ResNet-101 @ 1024x1024) checked through size-independent properties.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_golden import CASES, case_inputs  # noqa: E402
+
+
+def make_net(arch, opts, sd, dtype):
+    from dirtorch_amd import nets
+    net = nets.create_model(arch + '_rmac', pretrained='', **opts)
+    net.load_state_dict(sd)
+    net.compute_dtype = dtype
+    net.cuda()
+    return net.eval()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_descriptor_vs_reference_golden(case, dtype, model_goldens):
+    import dir_oracle as O
+    tag, arch, opts, gemp, B, H, W = case
+    sd, x = case_inputs(*case)
+    net = make_net(arch, opts, sd, dtype)
+    with torch.no_grad():
+        desc = net(x.cuda())
+    torch.cuda.synchronize()
+    gold = model_goldens[tag + '.desc']
+    got = desc.cpu().numpy()
+    assert got.shape == gold.shape, (got.shape, gold.shape)     # (D,) when B == 1
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(np.linalg.norm(got.reshape(-1, got.shape[-1]), axis=1), 1.0, atol=1e-5)
+    cos = O.cosine(got, gold)
+    assert np.all(1 - cos < 1e-4), '%s %s: 1-cos = %s' % (tag, dtype, 1 - cos)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('arch,H,W', [('resnet18', 64, 80), ('resnet50', 97, 75)])
+def test_trunk_features_vs_quantised_oracle(arch, H, W, dtype):
+    import dir_oracle as O
+    sd = O.synth_state_dict(arch, seed=7)
+    x = O.synth_images(11, 2, H, W)
+    net = make_net(arch, {}, sd, dtype)
+    feat = net.forward_features(x.cuda()).float().cpu().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        ref = O.resnet_features(sd, arch, x, quant=dtype)
+        ref32 = O.resnet_features(sd, arch, x)
+    assert feat.shape == ref.shape
+    rel = float((feat - ref).norm() / ref.norm())
+    rel32 = float((feat - ref32).norm() / ref32.norm())
+    # vs the emulation only accumulation order and rare 1-ulp flips differ
+    assert rel < (2e-3 if dtype == 'bf16' else 3e-4), (rel, rel32)
+    assert rel32 < (2e-2 if dtype == 'bf16' else 3e-3), rel32
+
+
+def test_uint8_input_path_matches_float_path():
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet18', seed=7)
+    net = make_net('resnet18', {}, sd, 'fp16')
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (2, 70, 90, 3), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor(net.rgb_means), torch.tensor(net.rgb_stds)
+    xf = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
+    a = net(u8.cuda()).cpu().numpy()
+    b = net(xf.cuda()).cpu().numpy()
+    assert np.all(1 - O.cosine(a, b) < 1e-6)
+
+
+def test_batch_composition_is_irrelevant():
+    """Descriptor of an image does not depend on its batch neighbours (image-parallel sharding)."""
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet50', seed=7)
+    net = make_net('resnet50', {}, sd, 'bf16')
+    x = O.synth_images(3, 3, 96, 64).cuda()
+    full = net(x).cpu()
+    for i in range(3):
+        one = net(x[i:i + 1]).cpu()
+        assert one.shape == (2048,)
+        assert torch.equal(one, full[i]), i
+
+
+def test_workspace_and_argument_errors():
+    import ctypes
+    from dirtorch_amd import _lib
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet18', seed=7)
+    net = make_net('resnet18', {}, sd, 'bf16')
+    x = O.synth_images(3, 1, 64, 64).cuda()
+    net(x)
+    out = torch.empty(1, 2048, device='cuda')
+    small = torch.empty(1024, dtype=torch.uint8, device='cuda')
+    with pytest.raises(_lib.DirError) as ei:
+        _lib.call('dir_forward', net._engine, _lib.ptr(x), 1, 64, 64, 0, _lib.ptr(out), _lib.ptr(small),
+                  small.numel(), _lib.stream_ptr())
+    assert ei.value.code == -4 and 'workspace' in str(ei.value)
+    with pytest.raises(_lib.DirError):
+        net(torch.zeros(1, 3, 4, 4, device='cuda'))       # smaller than the 7x7 stem
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 4, 64, 64, device='cuda'))
+    # missing tensor is reported by name
+    bad = {k: v for k, v in sd.items() if k != 'layer2.0.bn1.running_var'}
+    net2 = make_net('resnet18', {}, sd, 'bf16')
+    net2.load_state_dict(bad, strict=False)
+    net2._state.pop('layer2.0.bn1.running_var')
+    e = ctypes.c_void_p()
+    with pytest.raises(_lib.DirError) as ei:
+        net2._engine = None
+        net2(x)
+    assert 'layer2.0.bn1' in str(ei.value)
+
+
+def test_baseline_size_forward_properties():
+    """ResNet-101 @ 1024x1024 (BASELINE config B) through properties that need no CPU oracle run:
+    unit norm, finiteness, batch-independence, determinism, and agreement of the autotuned
+    tile choice with the heuristic one (different tilings, same arithmetic up to summation order)."""
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet101', seed=7)
+    net = make_net('resnet101', {}, sd, 'bf16')
+    x = O.synth_images(4, 2, 1024, 1024).cuda()
+    d1 = net(x).cpu()
+    d2 = net(x).cpu()
+    assert d1.shape == (2, 2048) and torch.isfinite(d1).all()
+    assert torch.equal(d1, d2)
+    np.testing.assert_allclose(d1.norm(dim=1).numpy(), 1.0, atol=1e-5)
+    single = net(x[1:2]).cpu()
+    assert float(1 - (single * d1[1]).sum()) < 1e-6
+    net.autotune = True
+    d3 = net(x).cpu()
+    assert np.all(1 - O.cosine(d3.numpy(), d1.numpy()) < 1e-5)
+    # non-square, odd size (1023 x 767): the real workload is variable H x W
+    y = O.synth_images(5, 1, 1023, 767).cuda()
+    net.autotune = False
+    dy = net(y).cpu()
+    assert dy.shape == (2048,) and torch.isfinite(dy).all()

@@ -1,0 +1,331 @@
+"""Op-level parity on the MI355X: every HIP kernel, through the C ABI, against the CPU oracle
+(torch fp32 on the same 16-bit-rounded inputs) and against the committed golden vectors.
+
+Tolerances (stated per test): the kernels accumulate in fp32 and round once to 16 bits on store,
+so vs an fp32 reference of the SAME rounded inputs the error is one output rounding
+(bf16: 2^-8 relative, fp16: 2^-11) plus summation-order noise.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+RTOL = {'bf16': 1.0 / 128, 'fp16': 1.0 / 1024}
+
+
+def _ops():
+    from dirtorch_amd import ops
+    return ops
+
+
+def _variants():
+    # resolved lazily on the GPU box; at collection time without the library fall back to a range
+    try:
+        from dirtorch_amd import _lib
+        return list(range(_lib.load().dir_conv_variant_count()))
+    except Exception:
+        return list(range(12))
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def conv_reference(x_nhwc16, w16, bias, res16, stride, pad, relu):
+    """fp32 CPU conv of the 16-bit-rounded operands (NHWC in / NHWC out)."""
+    x = x_nhwc16.float().permute(0, 3, 1, 2)
+    w = w16.float().permute(0, 3, 1, 2)          # [Cout,R,S,Cin] -> OIHW
+    y = F.conv2d(x, w, bias, stride, pad)
+    if res16 is not None:
+        y = y + res16.float().permute(0, 3, 1, 2)
+    if relu:
+        y = F.relu(y)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def check_close(got16, ref32, dname, what):
+    got = got16.float().cpu()
+    err = (got - ref32).abs()
+    tol = RTOL[dname] * ref32.abs() + RTOL[dname] * ref32.abs().mean() + 1e-5
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[:8]
+        rows = sorted(set(int(i[0] * got.shape[1] * got.shape[2] + i[1] * got.shape[2] + i[2]) for i in bad.nonzero()))
+        chans = sorted(set(int(i[3]) for i in bad.nonzero()))
+        msg = ['%s: %d / %d elements out of tolerance (max err %.4g, ref rms %.4g)'
+               % (what, int(bad.sum()), bad.numel(), float(err.max()), float(ref32.pow(2).mean().sqrt())),
+               'first bad pixel-rows (m): %s ... count %d' % (rows[:16], len(rows)),
+               'first bad channels (n): %s ... count %d' % (chans[:16], len(chans))]
+        for i in idx:
+            i = tuple(int(v) for v in i)
+            msg.append('  at %s got %.5f ref %.5f' % (i, float(got[i]), float(ref32[i])))
+        pytest.fail('\n'.join(msg))
+
+
+# (name, B, H, W, Cin, Cout, k, stride, pad, residual, relu)
+CONV_SHAPES = [
+    ('1x1_tail', 2, 9, 7, 64, 64, 1, 1, 0, False, True),
+    ('1x1_k256', 3, 16, 16, 256, 128, 1, 1, 0, True, True),
+    ('1x1_wide', 1, 20, 15, 64, 256, 1, 1, 0, True, False),
+    ('3x3_s1', 2, 13, 11, 64, 64, 3, 1, 1, False, True),
+    ('3x3_s1_c128', 1, 17, 18, 128, 128, 3, 1, 1, False, True),
+    ('3x3_s2', 2, 15, 14, 128, 128, 3, 2, 1, False, True),
+    ('1x1_s2_ds', 2, 14, 13, 256, 512, 1, 2, 0, False, False),
+    ('3x3_multi_tile', 4, 20, 20, 64, 128, 3, 1, 1, True, True),
+]
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('variant', _variants())
+@pytest.mark.parametrize('shape', CONV_SHAPES, ids=[s[0] for s in CONV_SHAPES])
+def test_conv_variant_vs_oracle(shape, variant, dname):
+    ops = _ops()
+    name, B, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
+    names = ops.conv_variant_names()
+    if variant >= len(names):
+        pytest.skip('no such variant')
+    bn = int(names[variant].split('_')[0].split('x')[1])
+    if Cout % bn != 0:
+        pytest.skip('variant %s not admissible for Cout=%d' % (names[variant], Cout))
+    dt = DTYPES[dname]
+    x = _rand((B, H, W, Cin), 1).to(dt)
+    w = _rand((Cout, k, k, Cin), 2, (2.0 / (k * k * Cin)) ** 0.5).to(dt)
+    bias = _rand((Cout,), 3, 0.2)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _rand((B, OH, OW, Cout), 4).to(dt) if use_res else None
+    ref = conv_reference(x, w, bias, res, stride, pad, relu)
+    y = ops.conv_bn_act(x.cuda(), w.cuda(), bias.cuda(), None if res is None else res.cuda(),
+                        stride=stride, pad=pad, relu=relu, variant=variant)
+    torch.cuda.synchronize()
+    assert y.shape == (B, OH, OW, Cout)
+    check_close(y, ref, dname, '%s variant %s %s' % (name, names[variant], dname))
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+def test_naive_conv_vs_oracle(dname):
+    ops = _ops()
+    dt = DTYPES[dname]
+    x = _rand((2, 10, 9, 64), 5).to(dt)
+    w = _rand((64, 3, 3, 64), 6, 0.06).to(dt)
+    bias = _rand((64,), 7, 0.2)
+    res = _rand((2, 5, 5, 64), 8).to(dt)
+    ref = conv_reference(x, w, bias, res, 2, 1, True)
+    y = ops.conv_bn_act(x.cuda(), w.cuda(), bias.cuda(), res.cuda(), stride=2, pad=1, relu=True, naive=True)
+    check_close(y, ref, dname, 'naive conv')
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('hw', [(37, 41), (64, 64), (30, 23)])
+def test_stem_space_to_depth_vs_7x7(hw, dname):
+    """prep_input + 4x4 s1 conv over the space-to-depth image == Conv2d(3,64,7,stride 2,pad 3)."""
+    ops = _ops()
+    H, W = hw
+    dt = DTYPES[dname]
+    img = _rand((2, 3, H, W), 9)
+    w7 = _rand((64, 3, 7, 7), 10, (2.0 / (49 * 64)) ** 0.5 * 3)
+    bias = _rand((64,), 11, 0.1)
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    ref = F.relu(F.conv2d(img.to(dt).float(), w7.to(dt).float(), bias, 2, 3)).permute(0, 2, 3, 1).contiguous()
+    s2d = ops.prep_input(img.cuda(), dt)
+    assert s2d.shape == (2, (H + 1) // 2, (W + 1) // 2, 16)
+    # channel layout of the space-to-depth tensor: (dy*2+dx)*3 + c, 12..15 zero
+    s = s2d.float().cpu()
+    assert float(s[..., 12:].abs().max()) == 0.0
+    np.testing.assert_array_equal(s[0, 3, 2, 0:3].numpy(), img.to(dt).float()[0, :, 6, 4].numpy())
+    np.testing.assert_array_equal(s[1, 1, 5, 9:12].numpy(), img.to(dt).float()[1, :, 3, 11].numpy())
+    wp = ops.pack_stem_weight(w7, dt).cuda()
+    for variant in [v for v, n in enumerate(ops.conv_variant_names()) if 'x64_' in n]:
+        y = ops.conv_bn_act(s2d, wp, bias.cuda(), None, stride=1, pad=2, relu=True, out_hw=(OH, OW),
+                            variant=variant)
+        check_close(y, ref, dname, 'stem %dx%d variant %d' % (H, W, variant))
+
+
+def test_prep_input_uint8_normalises_like_totensor():
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    u8 = torch.randint(0, 256, (2, 21, 18, 3), generator=g, dtype=torch.uint8)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    # ToTensor (/255) then Normalize: dirtorch/utils/transforms.py:617-623
+    ref = (u8.float() / 255.0 - torch.tensor(mean)) / torch.tensor(std)      # NHWC
+    s2d = ops.prep_input(u8.cuda(), torch.float16, mean, std).float().cpu()
+    for (y, x) in [(0, 0), (5, 7), (20, 17), (13, 2)]:
+        c0 = ((y % 2) * 2 + (x % 2)) * 3
+        np.testing.assert_allclose(s2d[:, y // 2, x // 2, c0:c0 + 3].numpy(), ref[:, y, x].numpy(),
+                                   rtol=1e-3, atol=1e-3)
+    assert float(s2d[:, 10, :, 6:12].abs().max()) == 0.0   # row 21 does not exist (odd H): zeros
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('hw', [(16, 16), (15, 9), (7, 12)])
+def test_maxpool(hw, dname):
+    ops = _ops()
+    dt = DTYPES[dname]
+    x = _rand((2, hw[0], hw[1], 64), 13).to(dt)
+    ref = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    y = ops.maxpool_3x3s2(x.cuda()).float().cpu()
+    assert torch.equal(y, ref)   # max of 16-bit values is exact
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('mode,p,cb', [('gem', 3.0, 0.0), ('gem', 2.7, 0.0), ('max', 0.0, 0.0),
+                                       ('avg', 0.0, 0.0), ('gem', 3.0, 0.5), ('avg', 0.0, 1.5)])
+def test_global_pool(mode, p, cb, dname):
+    import dir_oracle as O
+    ops = _ops()
+    dt = DTYPES[dname]
+    x = (_rand((3, 7, 5, 128), 14).abs() * 2 - 0.3).to(dt)     # mostly positive, some below eps
+    xf = x.float().permute(0, 3, 1, 2)
+    if cb > 0:
+        xf = xf * O.center_bias_mask(cb, xf.shape[-2:])
+    if mode == 'gem':
+        ref = O.gem_pool(xf, p)
+    elif mode == 'max':
+        ref = F.adaptive_max_pool2d(xf, 1)
+    else:
+        ref = F.adaptive_avg_pool2d(xf, 1)
+    got = ops.global_pool(x.cuda(), mode, p if p else 3.0, 1e-6, cb).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.reshape(3, 128).numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_l2norm_rows_and_idempotence():
+    ops = _ops()
+    x = _rand((5, 2048), 15)
+    x[3] = 0.0
+    got = ops.l2norm_rows_(x.clone().cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), F.normalize(x, p=2, dim=1).numpy(), rtol=2e-6, atol=1e-7)
+    again = ops.l2norm_rows_(got.clone().cuda()).cpu()
+    np.testing.assert_allclose(again.numpy(), got.numpy(), rtol=1e-6, atol=1e-7)
+    assert float(got[3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('NP,NQ,K', [(2048, 1, 2048), (2048, 8, 2048), (96, 40, 96), (33, 7, 96),
+                                      (130, 70, 64), (257, 131, 128), (5, 200, 36)])
+def test_gemm_nt_f32(NP, NQ, K):
+    ops = _ops()
+    P = _rand((NP, K), 16)
+    Q = _rand((NQ, K), 17)
+    sub = _rand((K,), 18)
+    bias = _rand((NP,), 19)
+    alpha = _rand((NP,), 20).abs() + 0.5
+    ref = ((Q.double() - sub.double()) @ P.double().t()) * alpha.double() + bias.double()
+    got = ops.gemm_nt(P.cuda(), Q.cuda(), sub.cuda(), bias.cuda(), alpha.cuda()).cpu()
+    assert got.shape == (NQ, NP)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 2e-6 * scale * (K ** 0.5)
+    plain = ops.gemm_nt(P.cuda(), Q.cuda()).cpu()
+    ref2 = Q.double() @ P.double().t()
+    assert float((plain.double() - ref2).abs().max()) < 2e-6 * float(ref2.abs().max()) * (K ** 0.5)
+
+
+def test_gemm_nt_transpose_detecting():
+    # asymmetric operands: a row/column swap in the MFMA output mapping cannot pass
+    ops = _ops()
+    P = torch.zeros(64, 32)
+    Q = torch.zeros(40, 32)
+    for i in range(64):
+        P[i, i % 32] = 1.0 + i
+    for j in range(40):
+        Q[j, j % 32] = 100.0 + j
+    got = ops.gemm_nt(P.cuda(), Q.cuda()).cpu()
+    ref = Q @ P.t()
+    assert torch.equal(got, ref)
+
+
+def test_common_postproc_vs_reference_goldens(postproc_goldens):
+    """dirtorch_amd.utils.common.{pool, whiten_features, matmul} vs outputs of the reference's own
+    functions (tests/golden/postproc_goldens.npz)."""
+    import dir_oracle as O
+    from dirtorch_amd.utils import common
+    g = postproc_goldens
+    xs = [torch.from_numpy(a).cuda() for a in g['pool.in']]
+    assert common.pool(xs[:1]) is xs[0]
+    np.testing.assert_allclose(common.pool(xs, 'mean').cpu().numpy(), g['pool.mean'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(common.pool(xs, 'gem', 3).cpu().numpy(), g['pool.gem3'], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(common.pool(xs, 'gem', 2.5).cpu().numpy(), g['pool.gem2.5'], rtol=2e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        common.pool(xs, 'median')
+
+    pca = O.PCAParams(g['pca.mean'], g['pca.components'], g['pca.var'], True)
+    X = g['whiten.in']
+    # tolerance: fp32 GEMM of K=96 on data with |x - mean| ~ 0.1: 1e-4 cosine budget, we ask 1e-5 abs
+    np.testing.assert_allclose(common.whiten_features(X, pca, whitenp=0.5), g['whiten.p0.5'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(common.whiten_features(X, pca, whitenp=0.25, whitenv=32, whitenm=2.0),
+                               g['whiten.p0.25_v32_m2'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(common.whiten_features(X, pca, l2norm=False, whitenp=0.5), g['whiten.nol2'],
+                               rtol=1e-4, atol=1e-4)
+    got = common.matmul(g['matmul.A'], g['matmul.B'])
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == (7, 33)
+    np.testing.assert_allclose(got, g['matmul.np'], rtol=1e-5, atol=1e-5)
+    got_t = common.matmul(torch.from_numpy(g['matmul.A']).cuda(), torch.from_numpy(g['matmul.B']).cuda())
+    np.testing.assert_allclose(got_t, g['matmul.torch'], rtol=1e-5, atol=1e-5)
+    with pytest.raises(TypeError):   # torch x numpy raises in the reference too (common.py:37)
+        common.matmul(torch.from_numpy(g['matmul.A']), g['matmul.B'])
+
+
+def test_similarity_ranking_at_scale_matches_oracle_map():
+    """ROxford-sized ranking (70 x 4993 x 2048): identical mAP to the CPU oracle's np.dot path."""
+    import dir_oracle as O
+    from dirtorch_amd.utils import common
+    r = np.random.RandomState(21)
+    N, Q, D = 4993, 70, 2048
+    centers = r.standard_normal((Q, D)).astype(np.float32)
+    db = r.standard_normal((N, D)).astype(np.float32)
+    gnd = []
+    for q in range(Q):
+        idx = r.choice(N, 24, replace=False)
+        db[idx[:16]] += centers[q] * r.uniform(0.15, 0.6, (16, 1)).astype(np.float32)
+        gnd.append({'easy': sorted(idx[:6].tolist()), 'hard': sorted(idx[6:16].tolist()),
+                    'junk': sorted(idx[16:].tolist())})
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    qs = centers / np.linalg.norm(centers, axis=1, keepdims=True)
+    ref = O.matmul(qs, db)
+    got = common.matmul(qs, db)
+    assert got.shape == (Q, N)
+    assert np.abs(got - ref).max() < 5e-6
+    m_ref, m_got = O.mean_ap(ref, gnd), O.mean_ap(got, gnd)
+    for k in m_ref:
+        assert abs(m_ref[k] - m_got[k]) < 1e-3, (k, m_ref[k], m_got[k])   # gate: 0.1 mAP points = 1e-3
+
+
+# ---- BASELINE-size checks through a device-side checker + size-independent properties -----------
+BIG_SHAPES = [  # ResNet-101 @ 1024x1024 layer shapes (B = 1): name, H, W, Cin, Cout, k, stride, pad, res
+    ('layer1.conv2', 256, 256, 64, 64, 3, 1, 1, False),
+    ('layer1.conv3', 256, 256, 64, 256, 1, 1, 0, True),
+    ('layer2.0.conv2_s2', 256, 256, 128, 128, 3, 2, 1, False),
+    ('layer3.conv1', 64, 64, 1024, 256, 1, 1, 0, False),
+    ('layer3.conv2', 64, 64, 256, 256, 3, 1, 1, False),
+    ('layer4.0.downsample', 64, 64, 1024, 2048, 1, 2, 0, False),
+    ('layer4.conv2', 32, 32, 512, 512, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize('shape', BIG_SHAPES, ids=[s[0] for s in BIG_SHAPES])
+def test_conv_full_size_vs_device_checker(shape):
+    ops = _ops()
+    name, H, W, Cin, Cout, k, stride, pad, use_res = shape
+    dt = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(22)
+    x = torch.randn(1, H, W, Cin, generator=g, device='cuda').to(dt)
+    w = (torch.randn(Cout, k, k, Cin, generator=g, device='cuda') * (2.0 / (k * k * Cin)) ** 0.5).to(dt)
+    bias = torch.randn(Cout, generator=g, device='cuda') * 0.1
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(1, OH, OW, Cout, generator=g, device='cuda').to(dt) if use_res else None
+    ref = ops.conv_bn_act(x, w, bias, res, stride=stride, pad=pad, relu=True, naive=True).float()
+    names = ops.conv_variant_names()
+    for v, n in enumerate(names):
+        if Cout % int(n.split('_')[0].split('x')[1]) != 0:
+            continue
+        y = ops.conv_bn_act(x, w, bias, res, stride=stride, pad=pad, relu=True, variant=v).float()
+        err = (y - ref).abs()
+        tol = RTOL['bf16'] * ref.abs() + RTOL['bf16'] * ref.abs().mean()
+        nbad = int((err > tol).sum())
+        assert nbad == 0, '%s variant %s: %d bad of %d, max err %.4g' % (name, n, nbad, err.numel(), float(err.max()))
+    # linearity in the input (no bias / residual / ReLU): conv(2x) == 2 conv(x) exactly in 16-bit fp
+    zero = torch.zeros_like(bias)
+    y1 = ops.conv_bn_act(x, w, zero, None, stride=stride, pad=pad, relu=False).float()
+    y2 = ops.conv_bn_act((x.float() * 2).to(dt), w, zero, None, stride=stride, pad=pad, relu=False).float()
+    assert torch.equal(y2, y1 * 2)

@@ -1,0 +1,131 @@
+"""The CPU oracle (oracle/dir_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from /root/reference)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import dir_oracle as O
+
+# mirrors MODEL_CASES of tests/golden/make_golden.py
+CASES = [
+    ('r18_gem', 'resnet18', dict(), 2.7, 2, 96, 80),
+    ('r50_gem', 'resnet50', dict(), 2.7, 2, 97, 75),
+    ('r50_gem_b1', 'resnet50', dict(), 3.0, 1, 64, 64),
+    ('r50_max_norm', 'resnet50', dict(pooling='max', norm_features=True), None, 2, 64, 96),
+    ('r50_avg_cb', 'resnet50', dict(pooling='avg', center_bias=0.5, out_dim=512), None, 2, 64, 64),
+    ('r50_nofc', 'resnet50', dict(without_fc=True), 2.2, 2, 64, 64),
+    ('r101_gem', 'resnet101', dict(), 2.7, 1, 128, 96),
+]
+
+
+def case_inputs(tag, arch, opts, gemp, B, H, W):
+    sd = O.synth_state_dict(arch, seed=7, out_dim=opts.get('out_dim', 2048),
+                            gemp=gemp if gemp else 3.0, pooling=opts.get('pooling', 'gem'))
+    return sd, O.synth_images(11, B, H, W)
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_descriptor_matches_reference(case, model_goldens):
+    tag, arch, opts, gemp, B, H, W = case
+    sd, x = case_inputs(*case)
+    kw = {k: v for k, v in opts.items() if k != 'out_dim'}
+    with torch.no_grad():
+        feat = O.resnet_features(sd, arch, x)
+    desc = O.rmac_forward(sd, arch, x, **kw).numpy()
+    gold = model_goldens[tag + '.desc']
+    assert desc.shape == gold.shape            # (D,) when B == 1, like the reference's squeeze_
+    assert tuple(model_goldens[tag + '.feat_shape']) == tuple(feat.shape)
+    np.testing.assert_allclose(feat[:, ::64].numpy(), model_goldens[tag + '.feat_slice'],
+                               rtol=1e-4, atol=1e-4)
+    # same ops in the same order on the same CPU kernels: tolerance is thread-order noise only
+    assert np.abs(desc - gold).max() < 2e-6
+    assert np.all(O.cosine(desc, gold) > 1 - 1e-9)
+    np.testing.assert_allclose(np.linalg.norm(desc.reshape(-1, desc.shape[-1]), axis=1), 1.0, atol=1e-5)
+
+
+def test_folded_bn_equals_unfolded():
+    # the engine folds BatchNorm into the conv; the oracle's quant path does too - both must agree
+    sd = O.synth_state_dict('resnet18', seed=3)
+    x = O.synth_images(5, 1, 64, 64)
+    a = O.rmac_forward(sd, 'resnet18', x).numpy()
+    with torch.no_grad():
+        fa = O.resnet_features(sd, 'resnet18', x)
+        w, b = O._fold(sd, 'conv1.weight', 'bn1', None)
+        y1 = torch.nn.functional.conv2d(x, w, b, 2, 3)
+        y2 = O._conv_bn(sd, x, 'conv1.weight', 'bn1', 2, 3, None)
+    np.testing.assert_allclose(y1.numpy(), y2.numpy(), rtol=1e-4, atol=1e-4)
+    assert fa.shape == (1, 512, 2, 2) and a.shape == (2048,)
+
+
+def test_quant_emulation_is_close():
+    sd = O.synth_state_dict('resnet50', seed=7)
+    x = O.synth_images(11, 2, 64, 64)
+    ref = O.rmac_forward(sd, 'resnet50', x).numpy()
+    for q, tol in (('bf16', 1e-4), ('fp16', 2e-6)):
+        got = O.rmac_forward(sd, 'resnet50', x, quant=q).numpy()
+        assert np.all(1 - O.cosine(got, ref) < tol), (q, 1 - O.cosine(got, ref))
+
+
+def test_pool(postproc_goldens):
+    g = postproc_goldens
+    xs = [torch.from_numpy(a) for a in g['pool.in']]
+    assert O.pool(xs[:1]) is xs[0]
+    np.testing.assert_allclose(O.pool(xs, 'mean').numpy(), g['pool.mean'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(O.pool(xs, 'gem', 3).numpy(), g['pool.gem3'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(O.pool(xs, 'gem', 2.5).numpy(), g['pool.gem2.5'], rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        O.pool(xs, 'median')
+
+
+def test_whiten(postproc_goldens):
+    g = postproc_goldens
+    pca = O.PCAParams(g['pca.mean'], g['pca.components'], g['pca.var'], True)
+    X = g['whiten.in']
+    np.testing.assert_allclose(O.whiten_features(X, pca, whitenp=0.5), g['whiten.p0.5'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.whiten_features(X, pca, whitenp=0.25, whitenv=32, whitenm=2.0),
+                               g['whiten.p0.25_v32_m2'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.whiten_features(X, pca, l2norm=False, whitenp=0.5), g['whiten.nol2'],
+                               rtol=1e-5, atol=1e-5)
+
+
+def test_fit_pca_matches_sklearn_subspace(postproc_goldens):
+    # our SVD PCA spans the same components (up to sign) as the sklearn object in the golden file
+    r = np.random.RandomState(0)
+    X = r.standard_normal((200, 16)) @ np.diag(np.linspace(3, 0.5, 16))
+    p = O.fit_pca(X)
+    from sklearn.decomposition import PCA
+    s = PCA(whiten=True).fit(X)
+    np.testing.assert_allclose(p.explained_variance_, s.explained_variance_, rtol=1e-5)
+    np.testing.assert_allclose(np.abs(p.components_ @ s.components_.T), np.eye(16), atol=1e-4)
+
+
+def test_matmul(postproc_goldens):
+    g = postproc_goldens
+    np.testing.assert_allclose(O.matmul(g['matmul.A'], g['matmul.B']), g['matmul.np'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(O.matmul(g['matmul.A'], g['matmul.B']), g['matmul.torch'], rtol=1e-5, atol=1e-5)
+
+
+def test_average_precision(postproc_goldens):
+    g = postproc_goldens
+    for ranks, val in zip(g['ap.ranks'], g['ap.values']):
+        k = [int(v) for v in str(ranks).split(',') if v != '']
+        assert O.compute_average_precision(np.array(k)) == pytest.approx(val, abs=1e-12)
+    # derived known answers
+    assert O.compute_average_precision([0, 1, 2]) == 1.0
+    assert O.compute_average_precision([1, 3]) == pytest.approx(1 / 3)
+    assert O.compute_average_precision([]) == 0.0
+
+
+def test_eval_query_ap(postproc_goldens):
+    g = postproc_goldens
+    gnd = pickle.loads(g['evalap.gnd'][0])
+    scores = g['evalap.scores']
+    for q in range(scores.shape[0]):
+        d = O.eval_query_AP(scores[q], gnd[q]['easy'], gnd[q]['hard'], gnd[q]['junk'])
+        for mode in ('easy', 'medium', 'hard'):
+            assert d[mode] == pytest.approx(g['evalap.' + mode][q], abs=1e-12)
+    assert g['evalap.easy'][4] == -1
+    m = O.mean_ap(scores, gnd)
+    assert m['mAP-easy'] == pytest.approx(np.mean([v for v in g['evalap.easy'] if v >= 0]))
