@@ -170,6 +170,38 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         }
     };
 
+    // ---- epilogue operands fetched up front: their HBM latency hides under the whole K loop ----
+    constexpr int LPR = TN * 4;        // lanes covering one pixel row (8 channels each)
+    constexpr int RPP = 64 / LPR;      // pixel rows per pass
+    constexpr int NPASS = 32 / RPP;    // passes per 32-pixel strip
+    constexpr bool PRE_RES = (TM * NPASS <= 8);  // 16 B per lane each: at most 32 VGPRs
+    const int ecol = (lane % LPR) * 8;
+    const int erow = lane / LPR;
+    const int n_glob = tile_n * BN + wn * TN * 32 + ecol;
+    const int m_epi = tile_m * BM + wm * TM * 32;
+    float bias8[8];
+    {
+        const f32x4_t b0 = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_glob);
+        const f32x4_t b1 = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_glob + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bias8[e] = b0[e];
+            bias8[4 + e] = b1[e];
+        }
+    }
+    u32x4_t rres[PRE_RES ? TM : 1][PRE_RES ? NPASS : 1];
+    if (PRE_RES && a.res) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m = m_epi + j * 32 + pass * RPP + erow;
+                const int mc = m < a.M ? m : 0;   // clamped rows are never stored
+                rres[PRE_RES ? j : 0][PRE_RES ? pass : 0] =
+                    gload16(a.res + ((size_t)mc * a.Cout + n_glob));
+            }
+    }
+
     // ---- K loop: double-buffered, one barrier per K-step ----------------------------------------
     const int T = a.T;
     const int cpb = CIN16 ? 1 : (a.Cin >> 6);  // K-steps per filter tap
@@ -216,15 +248,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 
     // ---- epilogue: acc -> LDS (fp32, pixel-major) -> bias/residual/ReLU -> 16-byte stores -------
     char* ebase = smem + wave * (32 * EROW);
-    constexpr int LPR = TN * 4;    // lanes covering one pixel row (8 channels each)
-    constexpr int RPP = 64 / LPR;  // pixel rows per pass
-    const int ecol = (lane % LPR) * 8;
-    const int erow = lane / LPR;
-    const int n_glob = tile_n * BN + wn * TN * 32 + ecol;
-    float bias8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = a.bias[n_glob + e];
-
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
 #pragma unroll
@@ -240,18 +263,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int pass = 0; pass < 32 / RPP; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int mrow = pass * RPP + erow;
             const f32x4_t f0 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4);
             const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
-            const int m = tile_m * BM + (wm * TM + j) * 32 + mrow;
+            const int m = m_epi + j * 32 + mrow;
             if (m < a.M) {
                 float v[8] = {f0[0] + bias8[0], f0[1] + bias8[1], f0[2] + bias8[2],
                               f0[3] + bias8[3], f1[0] + bias8[4], f1[1] + bias8[5],
                               f1[2] + bias8[6], f1[3] + bias8[7]};
                 const size_t o = (size_t)m * a.Cout + n_glob;
                 if (a.res) {
-                    const u32x4_t rv = gload16(a.res + o);
+                    const u32x4_t rv = PRE_RES ? rres[PRE_RES ? j : 0][PRE_RES ? pass : 0]
+                                               : gload16(a.res + o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float lo, hi;
@@ -296,7 +320,10 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.tiles_m = ceil_div(a.M, BM);
     b.tiles_n = a.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(NT), LDS, stream, b);
+    // a single K-step never touches the second stage: ask for half the LDS, double the residency
+    const int one = (STAGE_BYTES > EPI_BYTES) ? STAGE_BYTES : EPI_BYTES;
+    const int lds = a.T > 1 ? LDS : one;
+    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(NT), lds, stream, b);
     return hipGetLastError();
 }
 

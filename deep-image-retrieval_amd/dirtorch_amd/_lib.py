@@ -85,6 +85,9 @@ def load():
             'HIP extension %s is missing - build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` or '
             'deep-image-retrieval_amd/csrc/build.sh; there is no CPU fallback.' % LIB_PATH)
+    # torch first: its bundled HIP runtime (libamdhip64) must be the one this library binds to,
+    # otherwise the process ends up with two runtimes and device pointers are not shared.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
