@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0}   # dense MFMA, MI355X_MICROARCH.md (no sparsity)
+PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.29 TB/s measured copy)
 GFLOP_PER_IMG = {('resnet101', 1024): 325.99, ('resnet50', 224): 8.183}
 
 
@@ -156,20 +157,30 @@ def main():
         conv_fl = sum(v[1] for k, v in fam.items() if k.startswith('conv_igemm'))
         dom = max((k for k in fam if k.startswith('conv_igemm')), key=lambda k: fam[k][0])
         dms, dfl, dby, dn = fam[dom]
-        achieved = dfl / (dms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
+        peak_tf = PEAK_TFLOPS[args.dtype]
+        tflops = dfl / (dms * 1e-3) / 1e12
+        gbs = dby / (dms * 1e-3) / 1e9
+        # which roof bounds the dominant kernel: its arithmetic intensity vs the machine balance
+        # (2.5 PF dense / 8 TB/s = 312 FLOP/B; MI355X_MICROARCH.md)
+        hbm_bound = (dfl / dby) < (peak_tf * 1e12) / (PEAK_HBM_GBS * 1e9)
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # PMC-derived HBM bytes / launch, if collected
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # PMC-derived HBM bytes / launch (scripts/summarize_prof.py)
         if os.path.isfile(tfile):
             try:
                 traffic = json.load(open(tfile)).get(dom)
             except Exception:
                 traffic = None
-        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak,
-                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+        roof = {'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': dom,
+                'achieved': round(gbs if hbm_bound else tflops, 2),
+                'peak': PEAK_HBM_GBS if hbm_bound else peak_tf,
+                'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / peak_tf, 4),
+                'traffic': traffic,
                 'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
                 'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
+                'kernel_tflops': round(tflops, 2), 'kernel_gbs': round(gbs, 1),
                 'all_conv_tflops': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                'all_conv_mfma_frac': round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
                 'all_conv_ms_per_step': round(conv_ms / K, 4),
                 'all_kernels_ms_per_step': round(sum(v[0] for v in fam.values()) / K, 4)}
         if args.layers:

@@ -143,6 +143,45 @@ int dir_engine_autotune(dir_engine* e, int B, int H, int W, void* ws, size_t ws_
     DIR_CATCH
 }
 
+int dir_engine_tuning_export(const dir_engine* e, char* buf, size_t cap, size_t* needed) {
+    DIR_TRY
+    if (!e || !needed) return fail(DIR_ERR_INVALID, "tuning_export: null argument");
+    std::string out;
+    for (const ConvLayer& L : e->convs)
+        for (const auto& kv : L.tuned)
+            out += L.name + " " + std::to_string(kv.first) + " " + conv_variant(kv.second).name + "\n";
+    *needed = out.size() + 1;
+    if (buf && cap >= out.size() + 1) memcpy(buf, out.c_str(), out.size() + 1);
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_engine_tuning_import(dir_engine* e, const char* text) {
+    DIR_TRY
+    if (!e || !text) return fail(DIR_ERR_INVALID, "tuning_import: null argument");
+    std::string s(text);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t eol = s.find('\n', pos);
+        if (eol == std::string::npos) eol = s.size();
+        const std::string line = s.substr(pos, eol - pos);
+        pos = eol + 1;
+        if (line.empty()) continue;
+        const size_t a = line.find(' '), b = line.rfind(' ');
+        if (a == std::string::npos || b == a) return fail(DIR_ERR_INVALID, "tuning_import: bad line: " + line);
+        const std::string lname = line.substr(0, a), vname = line.substr(b + 1);
+        const long M = atol(line.substr(a + 1, b - a - 1).c_str());
+        int variant = -1;
+        for (int v = 0; v < conv_variant_count(); ++v)
+            if (vname == conv_variant(v).name) variant = v;
+        if (variant < 0) continue;   // a variant this build no longer has: fall back to the heuristic
+        for (ConvLayer& L : e->convs)
+            if (L.name == lname) L.tuned[M] = variant;
+    }
+    return DIR_OK;
+    DIR_CATCH
+}
+
 int dir_engine_set_profiling(dir_engine* e, int enabled) {
     if (!e) return fail(DIR_ERR_INVALID, "set_profiling: null engine");
     e->profiling = enabled != 0;

@@ -188,6 +188,23 @@ class ResNet_RMAC(object):
         self._dirty = False
         self._tuned = set()
         del lib
+        cache = os.environ.get('DIRTORCH_AMD_TUNE_CACHE')
+        if cache and os.path.isfile(cache):
+            self.import_tuning(open(cache).read())
+
+    def export_tuning(self):
+        """Autotuned tile choices as text ('layer M variant' lines)."""
+        need = ctypes.c_size_t()
+        call('dir_engine_tuning_export', self._engine, None, 0, ctypes.byref(need))
+        buf = ctypes.create_string_buffer(need.value)
+        call('dir_engine_tuning_export', self._engine, buf, need.value, ctypes.byref(need))
+        return buf.value.decode()
+
+    def import_tuning(self, text):
+        call('dir_engine_tuning_import', self._engine, text.encode())
+        for line in text.splitlines():
+            if line.startswith('#shape '):
+                self._tuned.add(tuple(int(v) for v in line.split()[1:4]))
 
     def _workspace(self, B, H, W):
         need = ctypes.c_size_t()
@@ -218,6 +235,11 @@ class ResNet_RMAC(object):
         if self.autotune and (B, H, W) not in self._tuned:
             call('dir_engine_autotune', self._engine, B, H, W, ptr(ws), ws.numel(), stream_ptr())
             self._tuned.add((B, H, W))
+            cache = os.environ.get('DIRTORCH_AMD_TUNE_CACHE')
+            if cache:
+                with open(cache, 'w') as f:
+                    f.write(''.join('#shape %d %d %d\n' % s for s in sorted(self._tuned)))
+                    f.write(self.export_tuning())
         return x, B, H, W, fmt, ws
 
     def forward(self, x):

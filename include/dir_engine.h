@@ -105,6 +105,10 @@ int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, in
  * layer shape of a B x H x W forward and keep the fastest (synchronises).  Optional. */
 int dir_engine_autotune(dir_engine* e, int B, int H, int W, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* Tuned choices as text, one "layer M variant-name" line each, so a later process (e.g. a
+ * profiler run) can reuse them without re-timing.  export: *needed = bytes incl. NUL. */
+int dir_engine_tuning_export(const dir_engine* e, char* buf, size_t cap, size_t* needed);
+int dir_engine_tuning_import(dir_engine* e, const char* text);
 
 /* ---- per-launch profile (HIP events on the launch stream) ---------------------------------- */
 typedef struct dir_prof_record {
