@@ -244,8 +244,6 @@ static int fill_conv_args(ConvArgs& a, const void* x, const void* w, const float
     a.bias = bias;
     a.res = (const uint16_t*)res;
     a.y = (uint16_t*)y;
-    a.zero = zero_page();
-    if (!a.zero) return fail(DIR_ERR_HIP, "conv: zero page allocation failed");
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
     a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.relu = relu ? 1 : 0;
     a.M = B * OH * OW;

@@ -7,36 +7,59 @@
 //   m = (b, oh, ow) output pixel, n = output channel, k = (r, s, c) filter tap x input channel.
 //   X is never materialised: for K-step (r, s, c0..c0+63) the 64-channel slice of input pixel
 //   (oh*stride + r - pad, ow*stride + s - pad) is one contiguous 128-byte run of the NHWC tensor.
-//   Out-of-image taps read a 16-byte device zero page instead (zero padding).
 //   The stem (7x7 s2, Cin = 3) arrives as a 4x4 s1 convolution over the 2x2 space-to-depth image
 //   (Cin = 16): one K-step = one filter row = four neighbouring pixels = the same 128-byte run.
 //
-// Tile: BM output pixels x BN output channels per workgroup, K-step 64.  LDS holds two stages of
-//   X-tile [BM][64] + W-tile [BN][64] 16-bit, rows of 128 B, 16-byte chunks XOR-swizzled with
-//   ((row >> 1) & 7) so the MFMA fragment reads (ds_read_b128: row = lane & 31, chunk = 2*ks + lane/32)
-//   are bank-conflict free.  Staging is either LDS-DMA (global_load_lds_dwordx4; destination is
-//   lane-linear, so the swizzle is applied to the per-lane SOURCE chunk) or through registers.
+// Data movement: HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) through two buffer
+//   descriptors (activations, weights).  Per lane the 32-bit byte offset is computed ONCE; the
+//   K-step advances through the instruction's scalar offset, so a 1x1 convolution spends no
+//   VALU work per load.  Zero padding and the ragged last pixel tile use the descriptor's
+//   bounds check: an out-of-range offset makes the hardware write zeros.
+// LDS: an NST-slot ring of stages; a stage = X-tile [BM][64] + W-tile [BN][64], rows of 128 B whose
+//   16-byte chunks are XOR-swizzled with ((row >> 1) & 7) so the MFMA fragment reads (ds_read_b128:
+//   row = lane & 31, chunk = 2*ks + lane/32) are bank-conflict free.  The DMA destination is
+//   lane-linear, so the swizzle is applied to the per-lane SOURCE chunk.  Waits are counted
+//   (vmcnt = loads per stage x stages still in flight) and the barrier is the raw s_barrier, so
+//   later stages stay in flight across it.
 // MFMA operand roles are swapped (A = weights, B = pixels) so each lane ends up holding 4
-//   consecutive output channels of one pixel; the epilogue stages the wave's accumulators through
-//   LDS as fp32 and writes whole 16-byte runs (8 channels) with bias / residual / ReLU fused.
+//   consecutive output channels of one pixel.  Accumulators start at the folded-BN bias; the
+//   epilogue stages them through LDS (fp32) and emits whole 16-byte runs (8 channels) with
+//   residual add / ReLU / v_cvt_pk conversion fused.  Residual tiles are fetched before the K loop.
 #include "dir_common.h"
 #include "conv_igemm.h"
 
 namespace dir {
 
-template <class DT, int BM, int BN, int WGM, int WGN, int STG, bool CIN16>
+// voffset beyond any descriptor (tensors are < 2^31 bytes): the DMA writes zeros.  2^31 cannot wrap
+// in 32 bits when the scalar K offset is added, whichever way the bounds check treats soffset.
+static constexpr uint32_t kOOB = 0x80000000u;
+
+// 16 bytes per lane, global/L2 -> LDS at (wave-uniform `lds`) + lane * 16; `soff` rides in an SGPR.
+// (Kept in a __device__ function: used directly inside the kernel template's lambda, hipcc 7.2
+// silently drops the kernel's host stub.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
+}
+
+__device__ inline uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shr) {
+    return mul ? (__umulhi(n, mul) >> shr) : n;  // mul == 0 encodes division by 1
+}
+
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, bool CIN16>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvArgs a) {
+    static_assert(NST >= 2 && NST <= 4, "ring depth");
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TM = BM / WGM / 32;  // pixel (B-operand) tiles per wave
     constexpr int TN = BN / WGN / 32;  // channel (A-operand) tiles per wave
-    constexpr int NA = BM * 8 / NT;    // 16-byte X chunks per thread per stage
-    constexpr int NB = BN * 8 / NT;    // 16-byte W chunks per thread per stage
+    constexpr int NA = BM * 8 / NT;    // 16-byte X chunks per lane per stage
+    constexpr int NB = BN * 8 / NT;    // 16-byte W chunks per lane per stage
+    constexpr int LPS = NA + NB;       // DMA instructions per lane per stage
     static_assert(TM >= 1 && TN >= 1, "wave tile");
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "chunk split");
-    static_assert((NT / 8) % 16 == 0, "swizzle term must be constant per thread");
-    constexpr int XS = BM * 128;             // bytes of the X tile of one stage
+    static_assert((NT / 8) % 16 == 0, "swizzle term must be constant per lane");
+    constexpr int XS = BM * 128;  // bytes of the X tile of one stage
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int EROW = TN * 128 + 16;      // epilogue: one pixel row of TN*32 fp32 + pad
+    constexpr int EROW = TN * 128 + 16;  // epilogue: one pixel row of TN*32 fp32 + pad
     typedef typename DT::frag_t frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -44,114 +67,108 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WGN;
+    const int wm = wave / WGN;
+    const int lrow = lane & 31;
+    const int lhi = lane >> 5;
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = wg % a.tiles_n;  // n fastest: blocks sharing an X tile run on one XCD
     const int tile_m = wg / a.tiles_n;
 
-    // ---- per-thread source bookkeeping (constant over the K loop) -------------------------------
-    const int slot = tid & 7;
-    const int srcchunk = slot ^ ((tid >> 4) & 7);
-    int xoff[NA];
-    uint32_t xmask[NA];
-    const int OHW = a.OH * a.OW;
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+    // ---- per-lane source offsets (constant over the K loop) --------------------------------------
+    const int srcchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const bool one_tap = (a.R * a.S == 1);  // 1x1: no padding, K advances through the scalar offset
+    int xbase[NA];       // byte offset of tap (0,0), channel chunk `srcchunk` (may be negative)
+    uint32_t xmask[NA];  // bit per tap (stem: per filter row): tap inside the image and row valid
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int row = i * (NT / 8) + (tid >> 3);
         const int m = tile_m * BM + row;
         const bool mvalid = m < a.M;
-        const int mm = mvalid ? m : 0;
-        const int b = mm / OHW;
-        const int rem = mm - b * OHW;
-        const int oh = rem / a.OW;
-        const int ow = rem - oh * a.OW;
-        const int ih0 = oh * a.stride - a.pad;
-        const int iw0 = ow * a.stride - a.pad;
-        xoff[i] = ((b * a.H + ih0) * a.W + iw0) * a.Cin + srcchunk * 8;
-        uint32_t mask = 0;
-        if (CIN16) {
-            const int sp = srcchunk >> 1;  // which of the 4 pixels of the filter row this chunk is
-            const bool wok = (unsigned)(iw0 + sp) < (unsigned)a.W;
-            for (int r = 0; r < a.R; ++r)
-                if (mvalid && wok && (unsigned)(ih0 + r) < (unsigned)a.H) mask |= 1u << r;
+        if (a.flat) {  // 1x1, stride 1: output pixel m reads input pixel m
+            xbase[i] = (m * a.Cin + srcchunk * 8) * 2;
+            xmask[i] = mvalid ? 1u : 0u;
         } else {
+            const uint32_t mm = mvalid ? (uint32_t)m : 0u;
+            const uint32_t b = fast_div(mm, a.div_ohw_mul, a.div_ohw_shr);
+            const uint32_t rem = mm - b * (uint32_t)(a.OH * a.OW);
+            const uint32_t oh = fast_div(rem, a.div_ow_mul, a.div_ow_shr);
+            const uint32_t ow = rem - oh * (uint32_t)a.OW;
+            const int ih0 = (int)oh * a.stride - a.pad;
+            const int iw0 = (int)ow * a.stride - a.pad;
+            xbase[i] = (((int)b * a.H + ih0) * a.W + iw0) * a.Cin * 2 + srcchunk * 16;
+            // validity bits: rows r with 0 <= ih0+r < H, columns s with 0 <= iw0+s < W
+            uint32_t rbits = 0, cbits = 0;
             for (int r = 0; r < a.R; ++r)
+                if ((unsigned)(ih0 + r) < (unsigned)a.H) rbits |= 1u << r;
+            if (CIN16) {
+                // one K-step per filter row; this lane's chunk is pixel (srcchunk >> 1) of the row
+                const bool wok = (unsigned)(iw0 + (srcchunk >> 1)) < (unsigned)a.W;
+                xmask[i] = (mvalid && wok) ? rbits : 0u;
+            } else {
                 for (int s = 0; s < a.S; ++s)
-                    if (mvalid && (unsigned)(ih0 + r) < (unsigned)a.H &&
-                        (unsigned)(iw0 + s) < (unsigned)a.W)
-                        mask |= 1u << (r * a.S + s);
+                    if ((unsigned)(iw0 + s) < (unsigned)a.W) cbits |= 1u << s;
+                uint32_t mask = 0;
+                for (int r = 0; r < a.R; ++r)
+                    if ((rbits >> r) & 1u) mask |= cbits << (r * a.S);
+                xmask[i] = mvalid ? mask : 0u;
+            }
         }
-        xmask[i] = mask;
     }
-    int woff[NB];
+    uint32_t xvoff[NA];  // 1x1 path: final voffset with the row mask folded in
+#pragma unroll
+    for (int i = 0; i < NA; ++i) xvoff[i] = (xmask[i] & 1u) ? (uint32_t)xbase[i] : kOOB;
+    uint32_t wvoff[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int row = i * (NT / 8) + (tid >> 3);
-        woff[i] = (tile_n * BN + row) * a.Ktot + srcchunk * 8;
+        wvoff[i] = (uint32_t)(((tile_n * BN + row) * a.Ktot + srcchunk * 8) * 2);
     }
 
-    // ---- staging ------------------------------------------------------------------------------
-    u32x4_t xr[STG == STG_REG ? NA : 1];
-    u32x4_t wr[STG == STG_REG ? NB : 1];
-    (void)xr;
-    (void)wr;
-
-    // K-step t covers filter tap index `tap` (= r*S+s, or r for the stem) and channels c0..c0+63.
+    // K-step t: filter tap `tap` (stem: filter row), byte offset `koff` of that tap/channel slice
     auto issue = [&](int t, int tap, int koff, char* stage) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const bool ok = (xmask[i] >> tap) & 1u;
-            const uint16_t* src = ok ? a.x + (xoff[i] + koff) : a.zero;
-            if (STG == STG_GLDS) {
-                __builtin_amdgcn_global_load_lds((const DIR_GLOBAL void*)src,
-                                                 (DIR_LDS void*)(stage + (i * NT + wave * 64) * 16),
-                                                 16, 0, 0);
+            char* dst = stage + (i * NT + wave * 64) * 16;
+            if (one_tap) {
+                dma16(rsrc_x, dst, xvoff[i], koff);
             } else {
-                xr[STG == STG_REG ? i : 0] = gload16(src);
+                const uint32_t v = ((xmask[i] >> tap) & 1u) ? (uint32_t)(xbase[i] + koff) : kOOB;
+                dma16(rsrc_x, dst, v, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const uint16_t* src = a.w + (woff[i] + t * 64);
-            if (STG == STG_GLDS) {
-                __builtin_amdgcn_global_load_lds(
-                    (const DIR_GLOBAL void*)src,
-                    (DIR_LDS void*)(stage + XS + (i * NT + wave * 64) * 16), 16, 0, 0);
-            } else {
-                wr[STG == STG_REG ? i : 0] = gload16(src);
-            }
-        }
-    };
-    auto commit = [&](char* stage) {  // register staging only: registers -> LDS
-        if (STG == STG_REG) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-                *(u32x4_t*)(stage + (i * NT + tid) * 16) = xr[STG == STG_REG ? i : 0];
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                *(u32x4_t*)(stage + XS + (i * NT + tid) * 16) = wr[STG == STG_REG ? i : 0];
-        }
+        for (int i = 0; i < NB; ++i)
+            dma16(rsrc_w, stage + XS + (i * NT + wave * 64) * 16, wvoff[i], t * 128);
     };
 
     // ---- fragment read offsets -----------------------------------------------------------------
-    const int wn = wave % WGN;
-    const int wm = wave / WGN;
-    const int lrow = lane & 31;
-    const int lhi = lane >> 5;
     const int lswz = (lane >> 1) & 7;
     int loff[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) loff[ks] = lrow * 128 + (((2 * ks + lhi) ^ lswz) << 4);
-    const int xbase = (wm * TM * 32) * 128;
-    const int wbase = XS + (wn * TN * 32) * 128;
+    const int xfrag = (wm * TM * 32) * 128;
+    const int wfrag = XS + (wn * TN * 32) * 128;
 
+    // ---- accumulators start at the bias of their 4 consecutive channels -----------------------
     f32x16_t acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + tile_n * BN + wn * TN * 32 +
+                                                            i * 32 + 8 * g + 4 * lhi);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b4[e];
+        }
 
     auto compute = [&](const char* stage) {
 #pragma unroll
@@ -159,10 +176,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
             frag_t wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                wf[i] = *(const frag_t*)(stage + wbase + i * 4096 + loff[ks]);
+                wf[i] = *(const frag_t*)(stage + wfrag + i * 4096 + loff[ks]);
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                xf[j] = *(const frag_t*)(stage + xbase + j * 4096 + loff[ks]);
+                xf[j] = *(const frag_t*)(stage + xfrag + j * 4096 + loff[ks]);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -170,25 +187,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         }
     };
 
-    // ---- epilogue operands fetched up front: their HBM latency hides under the whole K loop ----
-    constexpr int LPR = TN * 4;        // lanes covering one pixel row (8 channels each)
-    constexpr int RPP = 64 / LPR;      // pixel rows per pass
-    constexpr int NPASS = 32 / RPP;    // passes per 32-pixel strip
-    constexpr bool PRE_RES = (TM * NPASS <= 8);  // 16 B per lane each: at most 32 VGPRs
+    // ---- residual tile fetched up front: its HBM latency hides under the whole K loop ----------
+    constexpr int LPR = TN * 4;                  // lanes covering one pixel row (8 channels each)
+    constexpr int RPP = 64 / LPR;                // pixel rows per pass
+    constexpr int NPASS = 32 / RPP;              // passes per 32-pixel strip
+    constexpr bool PRE_RES = (TM * NPASS <= 16); // 16 B per lane each: at most 64 VGPRs
     const int ecol = (lane % LPR) * 8;
     const int erow = lane / LPR;
     const int n_glob = tile_n * BN + wn * TN * 32 + ecol;
     const int m_epi = tile_m * BM + wm * TM * 32;
-    float bias8[8];
-    {
-        const f32x4_t b0 = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_glob);
-        const f32x4_t b1 = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_glob + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bias8[e] = b0[e];
-            bias8[4 + e] = b1[e];
-        }
-    }
     u32x4_t rres[PRE_RES ? TM : 1][PRE_RES ? NPASS : 1];
     if (PRE_RES && a.res) {
 #pragma unroll
@@ -196,18 +203,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int m = m_epi + j * 32 + pass * RPP + erow;
-                const int mc = m < a.M ? m : 0;   // clamped rows are never stored
+                const int mc = m < a.M ? m : 0;  // clamped rows are never stored
                 rres[PRE_RES ? j : 0][PRE_RES ? pass : 0] =
                     gload16(a.res + ((size_t)mc * a.Cout + n_glob));
             }
     }
 
-    // ---- K loop: double-buffered, one barrier per K-step ----------------------------------------
+    // ---- K loop: NST-slot ring fed by LDS-DMA ----------------------------------------------------
+    // Stages t+1 .. t+NST-1 stay in flight while stage t is consumed.  One barrier per K-step:
+    // passing it means (a) stage t has landed for every wave (each waited on its own counted vmcnt
+    // first), (b) every wave has finished reading slot (t-1) % NST, the slot refilled right after.
     const int T = a.T;
     const int cpb = CIN16 ? 1 : (a.Cin >> 6);  // K-steps per filter tap
     int tap = 0, cc = 0, r = 0, s = 0;         // state of the step being ISSUED
-    auto koff_now = [&]() {
-        return CIN16 ? (r * a.W * 16) : ((r * a.W + s) * a.Cin + cc * 64);
+    auto koff_now = [&]() {                    // bytes
+        return CIN16 ? (r * a.W * 32) : (((r * a.W + s) * a.Cin + cc * 64) * 2);
     };
     auto advance = [&]() {
         if (++cc == cpb) {
@@ -221,32 +231,40 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
             }
         }
     };
-
-    char* stage0 = smem;
-    char* stage1 = smem + STAGE_BYTES;
-    issue(0, tap, koff_now(), stage0);
-    advance();
-    commit(stage0);
-    if (STG == STG_GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = 0; t < T; ++t) {
-        char* cur = (t & 1) ? stage1 : stage0;
-        char* nxt = (t & 1) ? stage0 : stage1;
-        const bool more = (t + 1 < T);
-        if (more) {
-            issue(t + 1, tap, koff_now(), nxt);
+    int issued = 0;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) {
+        if (p < T) {
+            issue(p, tap, koff_now(), smem + p * STAGE_BYTES);
             advance();
+            ++issued;
         }
-        compute(cur);
-        if (more) {
-            commit(nxt);
-            if (STG == STG_GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
     }
+    int slot_c = 0;        // slot holding stage t
+    int slot_i = issued;   // slot the next issue goes to
+    if (slot_i == NST) slot_i = 0;
+    for (int t = 0; t < T; ++t) {
+        const int ahead = issued - 1 - t;  // stages issued beyond t: 0 .. NST-2
+        if (NST >= 4 && ahead >= 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPS) : "memory");
+        } else if (NST >= 3 && ahead == 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (issued < T) {
+            issue(issued, tap, koff_now(), smem + slot_i * STAGE_BYTES);
+            advance();
+            ++issued;
+            if (++slot_i == NST) slot_i = 0;
+        }
+        compute(smem + slot_c * STAGE_BYTES);
+        if (++slot_c == NST) slot_c = 0;
+    }
+    __syncthreads();  // all fragment reads done before the epilogue reuses the ring
 
-    // ---- epilogue: acc -> LDS (fp32, pixel-major) -> bias/residual/ReLU -> 16-byte stores -------
+    // ---- epilogue: acc -> LDS (fp32, pixel-major) -> residual / ReLU / convert -> 16-byte stores --
     char* ebase = smem + wave * (32 * EROW);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -269,9 +287,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
             const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
             const int m = m_epi + j * 32 + mrow;
             if (m < a.M) {
-                float v[8] = {f0[0] + bias8[0], f0[1] + bias8[1], f0[2] + bias8[2],
-                              f0[3] + bias8[3], f1[0] + bias8[4], f1[1] + bias8[5],
-                              f1[2] + bias8[6], f1[3] + bias8[7]};
+                float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
                 const size_t o = (size_t)m * a.Cout + n_glob;
                 if (a.res) {
                     const u32x4_t rv = PRE_RES ? rres[PRE_RES ? j : 0][PRE_RES ? pass : 0]
@@ -279,7 +295,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float lo, hi;
-                        unpack2<DT>(rv[e], lo, hi);
+                        DT::unpack(rv[e], lo, hi);
                         v[2 * e] += lo;
                         v[2 * e + 1] += hi;
                     }
@@ -290,7 +306,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
                 }
                 u32x4_t ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                 gstore16(a.y + o, ov);
             }
         }
@@ -301,15 +317,30 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 }
 
 // ---- variant table ----------------------------------------------------------------------------
-template <class DT, int BM, int BN, int WGM, int WGN, int STG, bool CIN16>
+static void fastdiv_init(uint32_t d, uint32_t& mul, uint32_t& shr) {
+    // q = umulhi(n, mul) >> shr is exact for 0 <= n < 2^31 (mul = ceil(2^(31+l) / d), l = ceil(log2 d))
+    if (d <= 1) {
+        mul = 0;
+        shr = 0;
+        return;
+    }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    const uint32_t p = 31 + l;
+    mul = (uint32_t)(((1ull << p) + d - 1) / d);
+    shr = p - 32;
+}
+
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, bool CIN16>
 static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TN = BN / WGN / 32;
     constexpr int EROW = TN * 128 + 16;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int EPI_BYTES = (NT / 64) * 32 * EROW;
-    constexpr int LDS = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
-    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, STG, CIN16>;
+    constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, CIN16>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -320,39 +351,48 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.tiles_m = ceil_div(a.M, BM);
     b.tiles_n = a.Cout / BN;
-    // a single K-step never touches the second stage: ask for half the LDS, double the residency
-    const int one = (STAGE_BYTES > EPI_BYTES) ? STAGE_BYTES : EPI_BYTES;
-    const int lds = a.T > 1 ? LDS : one;
+    b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
+    b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
+    b.flat = (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW);
+    fastdiv_init((uint32_t)(a.OH * a.OW), b.div_ohw_mul, b.div_ohw_shr);
+    fastdiv_init((uint32_t)a.OW, b.div_ow_mul, b.div_ow_shr);
+    // a short K loop never touches the far slots of the ring: ask for less LDS, more residency
+    const int used = (a.T < NST ? a.T : NST) * STAGE_BYTES;
+    const int lds = used > EPI_BYTES ? used : EPI_BYTES;
     hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(NT), lds, stream, b);
     return hipGetLastError();
 }
 
-#define DIR_VARIANT(BM, BN, WGM, WGN, STG, NAME)                                              \
-    {NAME, BM, BN, 64 * WGM * WGN, STG,                                                       \
-     {launch_variant<BF16, BM, BN, WGM, WGN, STG, false>,                                     \
-      launch_variant<FP16, BM, BN, WGM, WGN, STG, false>},                                    \
+#define DIR_VARIANT(BM, BN, WGM, WGN, NST, NAME)                                             \
+    {NAME, BM, BN, 64 * WGM * WGN, NST,                                                      \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, false>,                                    \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, false>},                                   \
      {nullptr, nullptr}}
 // BN == 64 variants also carry the Cin == 16 (space-to-depth stem) instantiation.
-#define DIR_VARIANT16(BM, BN, WGM, WGN, STG, NAME)                                            \
-    {NAME, BM, BN, 64 * WGM * WGN, STG,                                                       \
-     {launch_variant<BF16, BM, BN, WGM, WGN, STG, false>,                                     \
-      launch_variant<FP16, BM, BN, WGM, WGN, STG, false>},                                    \
-     {launch_variant<BF16, BM, BN, WGM, WGN, STG, true>,                                      \
-      launch_variant<FP16, BM, BN, WGM, WGN, STG, true>}}
+#define DIR_VARIANT16(BM, BN, WGM, WGN, NST, NAME)                                           \
+    {NAME, BM, BN, 64 * WGM * WGN, NST,                                                      \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, false>,                                    \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, false>},                                   \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, true>,                                     \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, true>}}
 
+// name = <pixels>x<channels>_w<waves m>x<waves n>[_s<ring depth>]
 static const ConvVariant kVariants[] = {
-    DIR_VARIANT(128, 128, 2, 2, STG_GLDS, "128x128_w2x2_glds"),
-    DIR_VARIANT(128, 128, 2, 2, STG_REG, "128x128_w2x2_reg"),
-    DIR_VARIANT16(128, 64, 2, 2, STG_GLDS, "128x64_w2x2_glds"),
-    DIR_VARIANT16(128, 64, 2, 2, STG_REG, "128x64_w2x2_reg"),
-    DIR_VARIANT16(256, 64, 4, 1, STG_GLDS, "256x64_w4x1_glds"),
-    DIR_VARIANT16(256, 64, 4, 1, STG_REG, "256x64_w4x1_reg"),
-    DIR_VARIANT(256, 128, 4, 2, STG_GLDS, "256x128_w4x2_glds"),
-    DIR_VARIANT(256, 128, 4, 2, STG_REG, "256x128_w4x2_reg"),
-    DIR_VARIANT(128, 256, 2, 4, STG_GLDS, "128x256_w2x4_glds"),
-    DIR_VARIANT(256, 256, 4, 2, STG_GLDS, "256x256_w4x2_glds"),
-    DIR_VARIANT(64, 128, 2, 2, STG_GLDS, "64x128_w2x2_glds"),
-    DIR_VARIANT16(64, 64, 2, 1, STG_GLDS, "64x64_w2x1_glds"),
+    DIR_VARIANT(128, 128, 2, 2, 2, "128x128_w2x2"),
+    DIR_VARIANT16(128, 64, 2, 2, 2, "128x64_w2x2"),
+    DIR_VARIANT16(256, 64, 4, 1, 2, "256x64_w4x1"),
+    DIR_VARIANT(256, 128, 4, 2, 2, "256x128_w4x2"),
+    DIR_VARIANT(128, 256, 2, 4, 2, "128x256_w2x4"),
+    DIR_VARIANT(256, 256, 4, 2, 2, "256x256_w4x2"),
+    DIR_VARIANT(64, 128, 2, 2, 2, "64x128_w2x2"),
+    DIR_VARIANT16(64, 64, 2, 1, 2, "64x64_w2x1"),
+    DIR_VARIANT(64, 128, 2, 2, 4, "64x128_w2x2_s4"),
+    DIR_VARIANT(128, 128, 2, 2, 3, "128x128_w2x2_s3"),
+    DIR_VARIANT16(128, 64, 2, 2, 4, "128x64_w2x2_s4"),
+    DIR_VARIANT16(64, 64, 2, 1, 4, "64x64_w2x1_s4"),
+    DIR_VARIANT(256, 128, 4, 2, 3, "256x128_w4x2_s3"),
+    DIR_VARIANT(128, 256, 2, 4, 3, "128x256_w2x4_s3"),
+    DIR_VARIANT16(256, 64, 4, 1, 3, "256x64_w4x1_s3"),
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -367,28 +407,26 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     return true;
 }
 
-// Heuristic: widest channel tile that divides Cout; pixel tile as large as still leaves at least
-// ~2 workgroups per CU (256 CUs) so the tail wave stays short.
+static int find_variant(int BM, int BN, int nst) {
+    for (int v = 0; v < kNumVariants; ++v)
+        if (kVariants[v].BM == BM && kVariants[v].BN == BN && kVariants[v].stages == nst) return v;
+    return -1;
+}
+
+// Heuristic used when a shape has not been autotuned (variable-size images, the reference's real
+// workload): widest channel tile that divides Cout, pixel tile as large as still leaves >= 2
+// workgroups per CU (256 CUs) so the tail wave stays short.
 int conv_pick_variant(const ConvArgs& a) {
-    const int order[] = {0, 2, 6, 4, 10, 11};  // glds family, big-first fallbacks below
-    (void)order;
-    auto tiles = [&](int v) {
-        return (long)ceil_div(a.M, kVariants[v].BM) * (a.Cout / kVariants[v].BN);
-    };
-    int cands[8];
-    int nc = 0;
-    if (a.Cout % 128 == 0) {
-        cands[nc++] = 6;   // 256x128
-        cands[nc++] = 0;   // 128x128
-        cands[nc++] = 10;  // 64x128
-    } else {
-        cands[nc++] = 4;   // 256x64
-        cands[nc++] = 2;   // 128x64
-        cands[nc++] = 11;  // 64x64
+    const int bn = (a.Cout % 128 == 0) ? 128 : 64;
+    const int bms[3] = {256, 128, 64};
+    int last = -1;
+    for (int i = 0; i < 3; ++i) {
+        const int v = find_variant(bms[i], bn, 2);
+        if (v < 0 || !conv_variant_admissible(v, a)) continue;
+        last = v;
+        if ((long)ceil_div(a.M, bms[i]) * (a.Cout / bn) >= 512) return v;
     }
-    for (int i = 0; i < nc; ++i)
-        if (tiles(cands[i]) >= 512) return cands[i];
-    return cands[nc - 1];
+    return last;
 }
 
 int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
@@ -401,9 +439,12 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
         return fail(DIR_ERR_INVALID, "conv: Cin must be a multiple of 64 (or 16 for the stem)");
     }
     if (a.R * a.S > 16) return fail(DIR_ERR_INVALID, "conv: at most 16 filter taps");
-    if ((long)a.B * a.H * a.W * a.Cin >= (1L << 31) || (long)a.M * a.Cout >= (1L << 31) ||
-        (long)a.Cout * a.Ktot >= (1L << 31))
-        return fail(DIR_ERR_INVALID, "conv: tensor exceeds 2^31 elements; lower the batch");
+    if ((long)a.B * a.H * a.W * a.Cin >= (1L << 30) || (long)a.M * a.Cout >= (1L << 30) ||
+        (long)a.Cout * a.Ktot >= (1L << 30))
+        return fail(DIR_ERR_INVALID, "conv: tensor exceeds 2^31 bytes; lower the batch");
+    if (((uintptr_t)a.x & 15) || ((uintptr_t)a.w & 15) || ((uintptr_t)a.y & 15) ||
+        ((uintptr_t)a.res & 15) || ((uintptr_t)a.bias & 15))
+        return fail(DIR_ERR_INVALID, "conv: tensors must be 16-byte aligned");
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv: bad dtype");
     if (variant < 0) variant = conv_pick_variant(a);
     if (!conv_variant_admissible(variant, a))

@@ -16,6 +16,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 #define DIR_GLOBAL __attribute__((address_space(1)))
 #define DIR_LDS __attribute__((address_space(3)))
@@ -66,6 +69,15 @@ struct BF16 {
     __device__ static inline f32x16_t mfma32(frag_t a, frag_t b, f32x16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // two packed values <-> floats in one or two VALU ops (v_cvt_pk_bf16_f32 rounds to nearest even)
+    __device__ static inline void unpack(uint32_t w, float& lo, float& hi) {
+        lo = __builtin_bit_cast(float, w << 16);
+        hi = __builtin_bit_cast(float, w & 0xffff0000u);
+    }
+    __device__ static inline uint32_t pack(float lo, float hi) {
+        const f32x2_t v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    }
 };
 struct FP16 {
     typedef f16x8_t frag_t;
@@ -74,6 +86,15 @@ struct FP16 {
     __host__ __device__ static inline uint16_t from_f32(float f) { return f32_to_f16_bits(f); }
     __device__ static inline f32x16_t mfma32(frag_t a, frag_t b, f32x16_t c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline void unpack(uint32_t w, float& lo, float& hi) {
+        const f32x2_t v = __builtin_convertvector(__builtin_bit_cast(f16x2_t, w), f32x2_t);
+        lo = v[0];
+        hi = v[1];
+    }
+    __device__ static inline uint32_t pack(float lo, float hi) {
+        const f32x2_t v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
     }
 };
 

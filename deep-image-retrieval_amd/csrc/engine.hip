@@ -24,16 +24,6 @@ int fail(int code, const std::string& msg) {
 }
 const char* last_error() { return g_err.c_str(); }
 
-static uint16_t* g_zero = nullptr;
-const uint16_t* zero_page() {
-    if (!g_zero) {
-        void* p = nullptr;
-        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-        g_zero = (uint16_t*)p;
-    }
-    return g_zero;
-}
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -207,7 +197,6 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMalloc((void**)&d_fc_b, fb->data.size() * 4));
         DIR_HIP_CHECK(hipMemcpy(d_fc_b, fb->data.data(), fb->data.size() * 4, hipMemcpyHostToDevice));
     }
-    if (!zero_page()) return fail(DIR_ERR_HIP, "could not allocate the zero page");
     DIR_HIP_CHECK(hipDeviceSynchronize());
     finalized = true;
     return DIR_OK;
@@ -310,7 +299,6 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
     a.bias = L.d_bias;
     a.res = res;
     a.y = y;
-    a.zero = zero_page();
     a.B = B;
     a.H = H;
     a.W = W;

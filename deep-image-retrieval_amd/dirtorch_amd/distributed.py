@@ -1,0 +1,109 @@
+"""Multi-GPU layout of the retrieval path: one process per GPU, image-parallel database shards,
+ONE all-gather of the per-shard descriptor blocks before ranking (BASELINE.json north_star,
+SURVEY.md §8e).
+
+The reference's only parallelism is single-process nn.DataParallel (dirtorch/utils/common.py:155),
+which is inert at its default batch size of 1.  Here rank r extracts the contiguous index range
+[r*N/W, (r+1)*N/W) with replicated weights (no communication), then every rank receives all shards
+with a single collective: RCCL all_gather_into_tensor over xGMI on GPUs ('nccl' backend), gloo on
+CPU tensors for the tests.  Shards are padded to equal row counts (the collective needs equal
+sizes) and trimmed after; the result is bit-identical to the single-process concatenation.
+"""
+import os
+
+import torch
+
+
+def is_initialized():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def rank():
+    return torch.distributed.get_rank() if is_initialized() else 0
+
+
+def world_size():
+    return torch.distributed.get_world_size() if is_initialized() else 1
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run);
+    no-op for a single process.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this driver
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            torch.distributed.init_process_group(backend)
+    return rank(), world_size(), local
+
+
+def shard_range(n, r=None, w=None):
+    """Contiguous index range of rank r among w ranks: [r*n//w, (r+1)*n//w)."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    return (r * n) // w, ((r + 1) * n) // w
+
+
+def allgather_rows(local, n_total):
+    """local: this rank's [hi-lo, D] block (rows shard_range(n_total)) -> the full [n_total, D]
+    on every rank, in dataset order.  One collective."""
+    w = world_size()
+    if w == 1:
+        assert local.shape[0] == n_total
+        return local
+    sizes = [shard_range(n_total, r, w) for r in range(w)]
+    lo, hi = sizes[rank()]
+    assert local.shape[0] == hi - lo, 'shard has %d rows, expected %d' % (local.shape[0], hi - lo)
+    rows = max(h - l for l, h in sizes)
+    D = local.shape[1]
+    padded = local.new_zeros((rows, D))
+    padded[:hi - lo] = local
+    if local.is_cuda:
+        out = local.new_empty((w * rows, D))
+        torch.distributed.all_gather_into_tensor(out, padded.contiguous())
+        parts = [out[r * rows:r * rows + (h - l)] for r, (l, h) in enumerate(sizes)]
+    else:
+        bufs = [local.new_empty((rows, D)) for _ in range(w)]
+        torch.distributed.all_gather(bufs, padded.contiguous())
+        parts = [bufs[r][:h - l] for r, (l, h) in enumerate(sizes)]
+    return torch.cat(parts, dim=0)
+
+
+class SubDataset(object):
+    """View of dataset[lo:hi] exposing what the loader touches (get_image / get_key / len)."""
+
+    def __init__(self, dataset, lo, hi):
+        self.dataset, self.lo, self.nimg = dataset, lo, hi - lo
+
+    def __len__(self):
+        return self.nimg
+
+    def get_image(self, i, *a, **k):
+        return self.dataset.get_image(self.lo + i, *a, **k)
+
+    def get_key(self, i):
+        return self.dataset.get_key(self.lo + i)
+
+    def get_label(self, i, *a, **k):
+        return self.dataset.get_label(self.lo + i, *a, **k)
+
+
+def extract_sharded(extract_fn, dataset, trfs, net, **kw):
+    """extract_fn(dataset, trfs, net, **kw) -> [N, D]; under torch.distributed each rank runs it on
+    its own shard and the blocks are all-gathered."""
+    if world_size() == 1:
+        return extract_fn(dataset, trfs, net, **kw)
+    n = len(dataset)
+    lo, hi = shard_range(n)
+    if hi > lo:
+        local = extract_fn(SubDataset(dataset, lo, hi), trfs, net, **kw)
+    else:
+        D = net.trunk_dim if getattr(net, 'without_fc', False) else net.out_dim
+        local = torch.empty((0, D), dtype=torch.float32, device='cuda' if net.iscuda else 'cpu')
+    return allgather_rows(local, n)

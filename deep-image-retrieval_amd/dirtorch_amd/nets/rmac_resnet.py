@@ -169,9 +169,11 @@ class ResNet_RMAC(object):
             d.pooling = POOLING['gem' if self.pooling.startswith('gem') else self.pooling]
             d.without_fc = int(bool(self.without_fc))
             d.center_bias = float(self.center_bias)
+            mean, std = self._norm_constants()
             for i in range(3):
-                d.mean[i] = self.rgb_means[i]
-                d.std[i] = self.rgb_stds[i]
+                d.mean[i] = mean[i]
+                d.std[i] = std[i]
+            self._built_norm = (mean, std)
             handle = ctypes.c_void_p()
             call('dir_engine_create', ctypes.byref(d), torch.cuda.current_device(),
                  ctypes.byref(handle))
@@ -206,6 +208,13 @@ class ResNet_RMAC(object):
             if line.startswith('#shape '):
                 self._tuned.add(tuple(int(v) for v in line.split()[1:4]))
 
+    def _norm_constants(self):
+        """mean/std used by the uint8 input path: net.preprocess wins (a checkpoint may carry its
+        own, test_dir.py:188), else the ImageNet defaults of resnet.py:110-111."""
+        pre = getattr(self, 'preprocess', None) or {}
+        return (tuple(float(v) for v in pre.get('mean', self.rgb_means)),
+                tuple(float(v) for v in pre.get('std', self.rgb_stds)))
+
     def _workspace(self, B, H, W):
         need = ctypes.c_size_t()
         call('dir_workspace_bytes', self._engine, B, H, W, ctypes.byref(need))
@@ -215,6 +224,9 @@ class ResNet_RMAC(object):
         return self._ws
 
     def _prepare(self, x):
+        if self._engine is not None and getattr(self, '_built_norm', None) != self._norm_constants():
+            _lib.load().dir_engine_destroy(self._engine)     # mean/std live in the engine's desc
+            self._engine = None
         if self._dirty or self._engine is None:
             self._build_engine()
         if not x.is_cuda:

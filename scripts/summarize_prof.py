@@ -20,11 +20,12 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d), (\w+)>', name)
+    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d), (?:(\d), )?(\w+)>', name)
     if m:
-        dt, bm, bn, wm, wn, stg, c16 = m.groups()
-        return 'conv_igemm<%sx%s_w%sx%s_%s>%s[%s]' % (bm, bn, wm, wn, 'glds' if stg == '0' else 'reg',
-                                                     '/stem' if c16 == 'true' else '', dt.lower())
+        dt, bm, bn, wm, wn, stg, nst, c16 = m.groups()
+        return 'conv_igemm<%sx%s_w%sx%s_%s%s>%s[%s]' % (bm, bn, wm, wn, 'glds' if stg == '0' else 'reg',
+                                                       '_s' + nst if nst and nst != '2' else '',
+                                                       '/stem' if c16 == 'true' else '', dt.lower())
     m = re.search(r'dir::(\w+)', name)
     if m:
         return m.group(1)

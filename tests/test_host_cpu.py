@@ -1,0 +1,194 @@
+"""Host-side logic that needs no GPU: datasets + AP protocol, transform DSL, shard arithmetic and
+the world_size-2 all-gather path over gloo (the N > 1 code path of bench.py / test_dir.py)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+
+# ---- datasets -----------------------------------------------------------------------------------
+def write_gnd(tmp_path, gnd, N):
+    gt = {'imlist': ['im%04d' % i for i in range(N)], 'qimlist': ['q%d' % i for i in range(len(gnd))],
+          'gnd': gnd}
+    f = os.path.join(str(tmp_path), 'gnd_synth.pkl')
+    with open(f, 'wb') as fh:
+        pickle.dump(gt, fh)
+    return f
+
+
+def test_eval_query_ap_matches_reference(tmp_path, postproc_goldens):
+    """ImageListRelevants.eval_query_AP vs the reference's own class run on the same pickle
+    (tests/golden/make_golden.py, dirtorch/datasets/generic.py:196-224)."""
+    from dirtorch_amd import datasets
+    g = postproc_goldens
+    gnd = pickle.loads(g['evalap.gnd'][0])
+    scores = g['evalap.scores']
+    db = datasets.ImageListRelevants(write_gnd(tmp_path, gnd, scores.shape[1]), root=str(tmp_path))
+    assert len(db) == 200 and db.nquery == 6 and db.get_key(3) == 'im0003.jpg'
+    qdb = db.get_query_db()
+    assert len(qdb) == 6 and qdb.get_roi(0) == (0, 0, 10, 10)
+    for q in range(db.nquery):
+        d = db.eval_query_AP(q, scores[q])
+        for mode in ('easy', 'medium', 'hard'):
+            assert d[mode] == pytest.approx(g['evalap.' + mode][q], abs=1e-12)
+    with pytest.raises(AssertionError):
+        db.eval_query_AP(0, scores[0][:-1])
+
+
+def test_classic_protocol_and_known_aps(tmp_path):
+    from dirtorch_amd import datasets
+    assert datasets.compute_average_precision([0, 1, 2]) == 1.0
+    assert datasets.compute_average_precision([1, 3]) == pytest.approx(1 / 3)
+    assert datasets.compute_average_precision([2, 5, 9]) == pytest.approx(0.2314814814814815)
+    assert datasets.compute_average_precision([]) == 0.0
+    gnd = [{'bbx': [0, 0, 1, 1], 'ok': [1, 3], 'junk': [0]}]
+    db = datasets.ImageListRelevants(write_gnd(tmp_path, gnd, 5), root=str(tmp_path))
+    # ranking by score: 4, 3, 2, 1 (0 is junk) -> positives at ranks 1 and 3
+    ap = db.eval_query_AP(0, np.array([9., 1., 2., 3., 4.]))
+    assert isinstance(ap, float) and ap == pytest.approx(datasets.compute_average_precision([1, 3]))
+
+
+def test_dataset_factory(tmp_path, monkeypatch):
+    from dirtorch_amd import datasets
+    lst = tmp_path / 'list.txt'
+    lst.write_text('a.png\nb.png\n\n')
+    db = datasets.create('ImageList("%s")' % lst)
+    assert len(db) == 2 and db.get_key(1) == 'b.png'
+    db = datasets.create('ImageList("%s", root="/data")' % lst)
+    assert db.get_filename(0) == '/data/a.png'
+    with pytest.raises(NotImplementedError):
+        db.get_query_db()
+    with pytest.raises(NameError):
+        datasets.create('Landmarks_clean')
+    with pytest.raises(SyntaxError):
+        datasets.create('ImageList(__import__("os").getcwd())')     # literals only, no eval
+    monkeypatch.delenv('DB_ROOT', raising=False)
+    with pytest.raises(KeyError):
+        datasets.create('ROxford5K')
+    monkeypatch.setenv('DB_ROOT', str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        datasets.create('RParis6K')
+
+
+# ---- transforms -----------------------------------------------------------------------------------
+def test_transform_dsl():
+    from PIL import Image
+    from dirtorch_amd.utils import transforms as T
+    img = Image.fromarray((np.arange(60 * 80 * 3) % 251).astype(np.uint8).reshape(60, 80, 3))   # w=80, h=60
+    pre = dict(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], input_size=224)
+    t = T.create('', to_tensor=True, **pre)(img)
+    assert t.shape == (3, 60, 80) and t.dtype == torch.float32
+    ref = (torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255
+           - torch.tensor(pre['mean']).view(3, 1, 1)) / torch.tensor(pre['std']).view(3, 1, 1)
+    assert torch.equal(t, ref)
+    u = T.create('', to_tensor='uint8', **pre)(img)
+    assert u.shape == (60, 80, 3) and u.dtype == torch.uint8
+    # Scale: smallest side -> size, int(0.5 + ...) rounding (transforms.py:147-170)
+    assert T.Scale(256).get_params((640, 480)) == (341, 256)
+    assert T.Scale(256, largest=True).get_params((640, 480)) == (256, 192)
+    assert T.Scale(0.5).get_params((641, 481)) == (321, 241)
+    assert T.Scale((32, 16)).get_params((640, 480)) == (32, 16)
+    assert T.create('Scale(30)', to_tensor='uint8', **pre)(img).shape == (30, 40, 3)
+    assert T.create('Scale(30), CenterCrop(24)', to_tensor='uint8', **pre)(img).shape == (24, 24, 3)
+    assert T.create('Pad(100)', to_tensor='uint8', **pre)(img).shape == (100, 80, 3)
+    assert T.create('PadSquare()', to_tensor='uint8', **pre)(img).shape == (80, 80, 3)
+    assert T.create('Scale(input_size)', to_tensor=True, **pre)(img).shape == (3, 224, 299)
+    with pytest.raises(SyntaxError):
+        T.create('RandomCrop(8)', **pre)
+    with pytest.raises(SyntaxError):
+        T.create('__import__("os").system("true")', **pre)
+
+
+def test_loader_batches_even_single_threaded(tmp_path):
+    from PIL import Image
+    from dirtorch_amd import datasets
+    from dirtorch_amd.utils.pytorch_loader import get_loader
+    names = []
+    for i in range(3):
+        Image.fromarray(np.full((20, 30, 3), 40 * i, np.uint8)).save(str(tmp_path / ('i%d.png' % i)))
+        names.append('i%d.png' % i)
+    db = datasets.ImageList(imgs=names, root=str(tmp_path))
+    pre = dict(mean=[0.5] * 3, std=[0.25] * 3, input_size=224)
+    batches = list(get_loader(db, '', False, preprocess=pre, output=['img'], batch_size=1, threads=1, shuffle=False))
+    assert len(batches) == 3 and batches[1][0].shape == (1, 20, 30, 3) and int(batches[2][0][0, 0, 0, 0]) == 80
+    fl = list(get_loader(db, '', False, preprocess=pre, output=['img'], batch_size=3, threads=0, shuffle=False,
+                         device_normalize=False))
+    assert fl[0][0].shape == (3, 3, 20, 30) and fl[0][0].dtype == torch.float32
+
+
+# ---- sharding + all-gather over gloo, world size 2 ------------------------------------------------
+def test_shard_ranges_cover_everything():
+    from dirtorch_amd.distributed import shard_range
+    for n in (0, 1, 2, 7, 70, 4993, 1006322):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def _fake_descs(lo, hi, D=16):
+    i = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1)
+    return torch.sin(i * 0.37 + torch.arange(D, dtype=torch.float32) * 1.3) * (1 + i / 7)
+
+
+class _FakeNet(object):
+    out_dim, iscuda, without_fc = 16, False, False
+
+
+class _FakeDB(object):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def get_key(self, i):
+        return i
+
+
+def _fake_extract(dataset, trfs, net, **kw):
+    keys = [dataset.get_key(i) for i in range(len(dataset))]
+    return _fake_descs(keys[0], keys[-1] + 1) if keys else torch.empty(0, 16)
+
+
+def _worker(rank, world, port, ns, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from dirtorch_amd import distributed as dd
+    r, w, _ = dd.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    res = {}
+    for n in ns:
+        lo, hi = dd.shard_range(n)
+        res[('gather', n)] = dd.allgather_rows(_fake_descs(lo, hi), n)
+        res[('extract', n)] = dd.extract_sharded(_fake_extract, _FakeDB(n), '', _FakeNet())
+    out[rank] = res
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_allgather_equals_single_process_concat_gloo_ws2():
+    import torch.multiprocessing as mp
+    ns = [1, 2, 7, 64, 4993]
+    port = 29000 + (os.getpid() % 2000)
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker, args=(2, port, ns, out), nprocs=2, join=True)
+        res = dict(out)
+    for n in ns:
+        full = _fake_descs(0, n)
+        for r in (0, 1):
+            assert torch.equal(res[r][('gather', n)], full), (n, r)       # bit-for-bit
+            assert torch.equal(res[r][('extract', n)], full), (n, r)
+
+
+def test_single_process_passthrough():
+    from dirtorch_amd import distributed as dd
+    x = _fake_descs(0, 9)
+    assert dd.allgather_rows(x, 9) is x
+    assert dd.rank() == 0 and dd.world_size() == 1
+    assert torch.equal(dd.extract_sharded(_fake_extract, _FakeDB(9), '', _FakeNet()), x)

@@ -1,0 +1,159 @@
+"""Pipeline- and CLI-level parity on the MI355X (SURVEY.md §4 levels 4-5):
+the drop-in entry points of dirtorch_amd (test_dir / extract_features) against the CPU oracle run
+over the same files, checkpoint (incl. a pickled sklearn PCA) and revisitop-format ground truth."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def save_images(root, names, sizes, seed):
+    from PIL import Image
+    r = np.random.RandomState(seed)
+    os.makedirs(root, exist_ok=True)
+    for name, (h, w) in zip(names, sizes):
+        yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing='ij')
+        img = np.stack([127 + 100 * np.sin(r.uniform(2, 9) * yy * 6.28 + r.uniform(0, 6)) *
+                        np.cos(r.uniform(2, 9) * xx * 6.28) + 20 * r.standard_normal((h, w)) for _ in range(3)], -1)
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(os.path.join(root, name))
+
+
+def oracle_descriptors(sd, arch, files, rois=None):
+    """What the reference computes per image: PIL RGB (-> crop) -> ToTensor -> Normalize -> net."""
+    import dir_oracle as O
+    from PIL import Image
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    out = []
+    for i, f in enumerate(files):
+        img = Image.open(f).convert('RGB')
+        if rois is not None:
+            img = img.crop(rois[i])
+        x = (torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255 - mean) / std
+        out.append(O.rmac_forward(sd, arch, x[None]).reshape(1, -1))
+    return torch.cat(out, 0)
+
+
+def make_checkpoint(path, arch, sd, pca):
+    torch.save({'model_options': dict(arch=arch + '_rmac', out_dim=2048, pooling='gem', gemp=3),
+                'state_dict': {'module.' + k: v for k, v in sd.items()},     # DataParallel-style keys
+                'pca': {'Landmarks_clean': pca}, 'epoch': 3}, path)
+
+
+def fitted_pca(seed=0, n=96, d=2048):
+    from sklearn.decomposition import PCA
+    r = np.random.RandomState(seed)
+    base = r.standard_normal((n, 24)).astype(np.float32) @ r.standard_normal((24, d)).astype(np.float32)
+    base += 0.05 * r.standard_normal((n, d)).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    return PCA(n_components=32, whiten=True).fit(base)
+
+
+def test_extract_features_cli(tmp_path):
+    """python -m dirtorch_amd.extract_features on an ImageList with whitening -> .npy"""
+    import dir_oracle as O
+    from dirtorch_amd import extract_features as ef
+    names = ['a.png', 'b.png', 'c.png', 'd.png', 'e.png']
+    sizes = [(96, 128), (130, 90), (64, 64), (101, 77), (80, 144)]        # variable H x W, odd sizes
+    save_images(str(tmp_path / 'imgs'), names, sizes, 1)
+    (tmp_path / 'list.txt').write_text('\n'.join(names) + '\n')
+    sd = O.synth_state_dict('resnet18', seed=7, gemp=3.0)
+    pca = fitted_pca()
+    ck = str(tmp_path / 'synth.pt')
+    make_checkpoint(ck, 'resnet18', sd, pca)
+    out = str(tmp_path / 'out' / 'feats.npy')
+    ef.main(['--dataset', 'ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'),
+             '--checkpoint', ck, '--output', out, '--gpu', '0', '--threads', '2',
+             '--whiten', 'Landmarks_clean', '--whitenp', '0.5'])
+    got = np.load(out)
+    ref = oracle_descriptors(sd, 'resnet18', [str(tmp_path / 'imgs' / n) for n in names]).numpy()
+    ref_w = O.whiten_features(ref, O.PCAParams(pca.mean_, pca.components_, pca.explained_variance_, True), whitenp=0.5)
+    assert got.shape == ref_w.shape == (5, 32)
+    # whitening subtracts the mean and rescales: it amplifies upstream error, so this is the strict gate
+    assert np.all(1 - O.cosine(got, ref_w) < 1e-4), 1 - O.cosine(got, ref_w)
+    # un-whitened descriptors too
+    out2 = str(tmp_path / 'raw.npy')
+    ef.main(['--dataset', 'ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'),
+             '--checkpoint', ck, '--output', out2, '--gpu', '0', '--threads', '0'])
+    raw = np.load(out2)
+    assert raw.shape == (5, 2048) and np.all(1 - O.cosine(raw, ref) < 1e-4)
+
+
+def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch):
+    """python -m dirtorch_amd.test_dir --dataset ROxford5K on a synthetic revisitop-format dataset:
+    mAP-easy/medium/hard within 0.1 points of the oracle pipeline."""
+    import dir_oracle as O
+    from dirtorch_amd import test_dir as td
+    root = tmp_path / 'oxford5k'
+    N, Q = 14, 3
+    r = np.random.RandomState(5)
+    names = ['im%02d' % i for i in range(N)]
+    sizes = [(int(r.randint(70, 130)), int(r.randint(70, 130))) for _ in range(N)]
+    save_images(str(root / 'jpg'), [n + '.jpg' for n in names], sizes, 2)
+    gnd = []
+    for q in range(Q):
+        perm = r.permutation(N)
+        h, w = sizes[q]
+        gnd.append({'bbx': [4, 6, w - 5, h - 3], 'easy': sorted(perm[:3].tolist()),
+                    'hard': sorted(perm[3:6].tolist()), 'junk': sorted(perm[6:8].tolist())})
+    with open(str(root / 'gnd_roxford5k.pkl'), 'wb') as f:
+        pickle.dump({'imlist': names, 'qimlist': names[:Q], 'gnd': gnd}, f)
+    monkeypatch.setenv('DB_ROOT', str(tmp_path))
+    sd = O.synth_state_dict('resnet18', seed=7, gemp=3.0)
+    pca = fitted_pca()
+    ck = str(tmp_path / 'synth.pt')
+    make_checkpoint(ck, 'resnet18', sd, pca)
+    js = str(tmp_path / 'res' / 'out.json')
+    res = td.main(['--dataset', 'ROxford5K', '--checkpoint', ck, '--gpu', '0', '--threads', '2',
+                   '--whiten', 'Landmarks_clean', '--whitenp', '0.25', '--out-json', js, '--detailed'])
+    files = [str(root / 'jpg' / (n + '.jpg')) for n in names]
+    bd = oracle_descriptors(sd, 'resnet18', files).numpy()
+    qd = oracle_descriptors(sd, 'resnet18', files[:Q], [tuple(g['bbx']) for g in gnd]).numpy()
+    P = O.PCAParams(pca.mean_, pca.components_, pca.explained_variance_, True)
+    scores = O.matmul(O.whiten_features(qd, P, whitenp=0.25), O.whiten_features(bd, P, whitenp=0.25))
+    ref = O.mean_ap(scores, gnd)
+    for k in ('mAP-easy', 'mAP-medium', 'mAP-hard'):
+        assert abs(res[k] - ref[k]) < 1e-3, (k, res[k], ref[k])       # 0.1 mAP points
+    assert len(res['APs-medium']) == Q and os.path.isfile(js)
+
+
+def test_eval_model_from_saved_features_matches_oracle(tmp_path):
+    """eval_model(load_feats=...) at ROxford5K size (70 x 4993): whiten + score on the GPU, AP on
+    the host; mAP identical to the oracle within 0.1 points."""
+    import dir_oracle as O
+    from dirtorch_amd import datasets, test_dir as td
+    r = np.random.RandomState(9)
+    N, Q, D = 4993, 70, 256
+    centers = r.standard_normal((Q, D)).astype(np.float32)
+    db = r.standard_normal((N, D)).astype(np.float32)
+    gnd = []
+    for q in range(Q):
+        idx = r.choice(N, 30, replace=False)
+        db[idx[:20]] += centers[q] * r.uniform(0.2, 0.8, (20, 1)).astype(np.float32)
+        gnd.append({'bbx': [0, 0, 1, 1], 'easy': sorted(idx[:8].tolist()), 'hard': sorted(idx[8:20].tolist()),
+                    'junk': sorted(idx[20:].tolist())})
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    qs = centers / np.linalg.norm(centers, axis=1, keepdims=True)
+    np.save(str(tmp_path / 'feats.bdescs.npy'), db)
+    np.save(str(tmp_path / 'feats.qdescs.npy'), qs)
+    with open(str(tmp_path / 'gnd.pkl'), 'wb') as f:
+        pickle.dump({'imlist': ['i%d' % i for i in range(N)], 'qimlist': ['q%d' % i for i in range(Q)], 'gnd': gnd}, f)
+    dset = datasets.ImageListRelevants(str(tmp_path / 'gnd.pkl'), root=str(tmp_path))
+    P = O.fit_pca(db[::7])
+
+    class Net(object):
+        iscuda, pca = True, P
+    res = td.eval_model(dset, Net(), '', whiten=dict(whitenp=0.25, whitenv=128, whitenm=1.0),
+                        load_feats=str(tmp_path))
+    sc = O.matmul(O.whiten_features(qs, P, whitenp=0.25, whitenv=128), O.whiten_features(db, P, whitenp=0.25, whitenv=128))
+    ref = O.mean_ap(sc, gnd)
+    for k in ref:
+        assert abs(res[k] - ref[k]) < 1e-3, (k, res[k], ref[k])
+    # alpha query expansion / DB augmentation run through the same kernels
+    res2 = td.eval_model(dset, Net(), '', whiten=None, load_feats=str(tmp_path), aqe=dict(k=3, alpha=2),
+                         adba=dict(k=2, alpha=1))
+    assert 0 < res2['mAP-medium'] <= 1
