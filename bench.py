@@ -81,7 +81,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--arch', default='resnet101')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'])

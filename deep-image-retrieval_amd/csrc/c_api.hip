@@ -317,6 +317,17 @@ int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out
     DIR_CATCH
 }
 
+int dir_rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P,
+                    int* counts, float* probe_scores, void* stream) {
+    DIR_TRY
+    if (Q < 0 || N < 0 || P < 0) return fail(DIR_ERR_INVALID, "rank_counts: negative size");
+    if (Q == 0 || N == 0 || P == 0) return DIR_OK;
+    if (!scores || !probe_idx || !counts || !probe_scores)
+        return fail(DIR_ERR_INVALID, "rank_counts: null pointer");
+    return rank_counts(scores, lds, Q, N, probe_idx, P, counts, probe_scores, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                         void* stream) {
     DIR_TRY

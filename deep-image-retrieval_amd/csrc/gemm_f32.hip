@@ -145,10 +145,69 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
     }
 }
 
+// Few Q rows (batch-sized FC: NQ <= 32): the MFMA tiling would leave 240 of 256 CUs idle, and the
+// job is a pure stream of P (NP*K*4 bytes, read once).  One wave per P row: the row lives in
+// registers (K/64 floats per lane, coalesced float4 loads), the NQ small Q rows come from L2, each
+// dot product is an fmaf chain + a 64-lane butterfly.  HBM-bound on P.
+template <int KV>  // float4 per lane: K <= KV * 256
+__global__ void __launch_bounds__(256) gemm_nt_small_kernel(const float* __restrict__ P, int ldp,
+                                                           const float* __restrict__ Q, int ldq,
+                                                           float* __restrict__ out, int ldo, int NP,
+                                                           int NQ, int K,
+                                                           const float* __restrict__ qsub,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= NP) return;
+    f32x4_t pv[KV], sv[KV];
+#pragma unroll
+    for (int c = 0; c < KV; ++c) {
+        const int k = (c * 64 + lane) * 4;
+        pv[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sv[c] = pv[c];
+        if (k < K) {
+            pv[c] = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)i * ldp + k);
+            if (qsub) sv[c] = *(const DIR_GLOBAL f32x4_t*)(qsub + k);
+        }
+    }
+    const float al = alpha ? alpha[i] : 1.f;
+    const float bi = bias ? bias[i] : 0.f;
+    for (int j = 0; j < NQ; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < KV; ++c) {
+            const int k = (c * 64 + lane) * 4;
+            if (k < K) {
+                const f32x4_t q = *(const DIR_GLOBAL f32x4_t*)(Q + (size_t)j * ldq + k) - sv[c];
+                s = fmaf(pv[c][0], q[0], s);
+                s = fmaf(pv[c][1], q[1], s);
+                s = fmaf(pv[c][2], q[2], s);
+                s = fmaf(pv[c][3], q[3], s);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) out[(size_t)j * ldo + i] = al * s + bi;
+    }
+}
+
 int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
                 int NQ, int K, const float* qsub, const float* bias, const float* alpha,
                 hipStream_t stream) {
     if (NP <= 0 || NQ <= 0) return DIR_OK;
+    if (NQ <= 32 && K <= 2048 && K > 0 && !(K & 3) && !(ldp & 3) && !(ldq & 3) &&
+        !((uintptr_t)P & 15) && !((uintptr_t)Q & 15) && !(qsub && ((uintptr_t)qsub & 15))) {
+        const unsigned blocks = (unsigned)ceil_div(NP, 4);
+        if (K <= 1024)
+            hipLaunchKernelGGL(gemm_nt_small_kernel<4>, dim3(blocks), dim3(256), 0, stream, P, ldp,
+                               Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha);
+        else
+            hipLaunchKernelGGL(gemm_nt_small_kernel<8>, dim3(blocks), dim3(256), 0, stream, P, ldp,
+                               Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha);
+        DIR_HIP_CHECK(hipGetLastError());
+        return DIR_OK;
+    }
     if (K <= 0 || (K & 3) || (ldp & 3) || (ldq & 3))
         return fail(DIR_ERR_INVALID, "gemm_nt_f32: K, ldp, ldq must be positive multiples of 4");
     if (((uintptr_t)P & 15) || ((uintptr_t)Q & 15) || ((uintptr_t)out & 15) ||

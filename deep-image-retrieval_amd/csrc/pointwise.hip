@@ -184,22 +184,39 @@ __global__ void __launch_bounds__(256) global_pool_kernel(const uint16_t* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = (POOL == DIR_POOL_MAX) ? -INFINITY : 0.f;
     const uint16_t* base = x + (size_t)b * HW * C + c0 + cl * 8;
-    for (int px = pr; px < HW; px += 32) {
-        const u32x4_t v = gload16(base + (size_t)px * C);
-        const float mk = cb > 0.f ? center_mask(px / W, px % W, H, W, cb) : 1.f;
+    // x^p for x >= eps > 0: p == 3 (the usual GeM exponent) is two multiplies, anything else
+    // exp2(p * log2 x) on the transcendental unit (inputs are clamped, so no denormal handling)
+    const bool cube = (p == 3.f);
+    auto powp = [&](float t) {
+        return cube ? t * t * t : __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(t));
+    };
+    constexpr int UNR = 4;  // 4 independent 16-byte loads in flight per lane
+    for (int px0 = pr; px0 < HW; px0 += 32 * UNR) {
+        u32x4_t v[UNR];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float f[2];
-            unpack2<DT>(v[e], f[0], f[1]);
+        for (int u = 0; u < UNR; ++u) {
+            const int px = px0 + 32 * u;
+            v[u] = gload16(base + (size_t)(px < HW ? px : pr) * C);
+        }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float t = f[q] * mk;
-                if (POOL == DIR_POOL_GEM)
-                    acc[2 * e + q] += powf(fmaxf(t, eps), p);
-                else if (POOL == DIR_POOL_MAX)
-                    acc[2 * e + q] = fmaxf(acc[2 * e + q], t);
-                else
-                    acc[2 * e + q] += t;
+        for (int u = 0; u < UNR; ++u) {
+            const int px = px0 + 32 * u;
+            if (px >= HW) break;
+            const float mk = cb > 0.f ? center_mask(px / W, px % W, H, W, cb) : 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f[2];
+                DT::unpack(v[u][e], f[0], f[1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float t = f[q] * mk;
+                    if (POOL == DIR_POOL_GEM)
+                        acc[2 * e + q] += powp(fmaxf(t, eps));
+                    else if (POOL == DIR_POOL_MAX)
+                        acc[2 * e + q] = fmaxf(acc[2 * e + q], t);
+                    else
+                        acc[2 * e + q] += t;
+                }
             }
         }
     }

@@ -70,6 +70,8 @@ SIGNATURES = {
     'dir_l2norm_rows': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     'dir_gemm_nt_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dir_rank_counts': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p]),
     'dir_multiscale_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                     c_void_p]),
 }

@@ -155,3 +155,17 @@ def multiscale_pool(xs, pooling='mean', gemp=3.0):
     out = torch.empty(N, D, dtype=torch.float32, device=xs.device)
     call('dir_multiscale_pool', ptr(xs), ptr(out), S, N, D, mode, float(gemp), stream_ptr())
     return out
+
+
+def rank_counts(scores, probe_idx):
+    """scores [Q,N] fp32 (CUDA), probe_idx [Q,P] int32 (-1 = unused) -> (counts [Q,P] int32,
+    probe_scores [Q,P] fp32): how many items rank before each probe (np.argsort(...)[::-1] order)."""
+    _need_cuda(scores, probe_idx)
+    if scores.dtype != torch.float32 or probe_idx.dtype != torch.int32:
+        raise TypeError('float32 scores and int32 probe indices expected')
+    Q, N = scores.shape
+    P = probe_idx.shape[1]
+    counts = torch.zeros(Q, P, dtype=torch.int32, device=scores.device)
+    pscores = torch.zeros(Q, P, dtype=torch.float32, device=scores.device)
+    call('dir_rank_counts', ptr(scores), N, Q, N, ptr(probe_idx), P, ptr(counts), ptr(pscores), stream_ptr())
+    return counts, pscores

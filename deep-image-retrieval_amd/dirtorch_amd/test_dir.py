@@ -132,12 +132,24 @@ def eval_model(db, net, trfs, pooling='mean', gemp=3, detailed=False, whiten=Non
     if aqe is not None:
         qdescs = expand_descriptors(qdescs, db=bdescs, **aqe)
 
-    scores = matmul(qdescs, bdescs)
+    # Large databases (>= 50k images, or DIRTORCH_AMD_DEVICE_RANK=1): keep the score matrix on the
+    # GPU and rank there (dirtorch_amd.ranking) instead of downloading it and argsort-ing every row.
+    flag = os.environ.get('DIRTORCH_AMD_DEVICE_RANK', 'auto')
+    device_rank = hasattr(db, 'junk') and (flag == '1' or (flag == 'auto' and len(db) >= 50000))
+    if device_rank:
+        from . import ranking
+        scores_dev = ranking.similarity_device(qdescs, bdescs)
+        scores = []          # no per-row host scores: top-k below is skipped like for label-less sets
+    else:
+        scores = matmul(qdescs, bdescs)
     del bdescs, qdescs
 
     res = {}
     try:
-        aps = [db.eval_query_AP(q, s) for q, s in enumerate(tqdm.tqdm(scores, desc='AP'))]
+        if device_rank:
+            aps = ranking.eval_aps_device(db, scores_dev)
+        else:
+            aps = [db.eval_query_AP(q, s) for q, s in enumerate(tqdm.tqdm(scores, desc='AP'))]
         if not isinstance(aps[0], dict):
             aps = [float(e) for e in aps]
             if detailed:
@@ -153,6 +165,8 @@ def eval_model(db, net, trfs, pooling='mean', gemp=3, detailed=False, whiten=Non
         print(" AP not implemented!")
 
     try:
+        if device_rank:
+            raise NotImplementedError()   # the revisitop datasets carry no labels (dataset.py:97)
         tops = [db.eval_query_top(q, s) for q, s in enumerate(tqdm.tqdm(scores, desc='top1'))]
         if detailed:
             res['tops'] = tops

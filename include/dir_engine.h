@@ -164,6 +164,14 @@ int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out
 int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                         void* stream);
 
+/* N1: ranking without sorting, for ImageListRelevants.eval_query_AP
+ * (dirtorch/datasets/generic.py:196-224).  For every query q and every probe p (a database index,
+ * -1 = unused slot) counts[q][p] = number of database items that rank before it under
+ * np.argsort(scores[q])[::-1]: score greater, or equal with a larger index.  probe_scores[q][p]
+ * receives scores[q][probe].  scores: [Q][N] fp32 with row stride lds; P <= 1024. */
+int dir_rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P,
+                    int* counts, float* probe_scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

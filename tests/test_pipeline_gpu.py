@@ -94,25 +94,36 @@ def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch):
     names = ['im%02d' % i for i in range(N)]
     sizes = [(int(r.randint(70, 130)), int(r.randint(70, 130))) for _ in range(N)]
     save_images(str(root / 'jpg'), [n + '.jpg' for n in names], sizes, 2)
+    # planted structure (random-weight descriptors of unrelated images are ~0.9996 cosine apart, the
+    # same order as 16-bit noise - SURVEY.md §7): positives are noisy copies of the query image
+    from PIL import Image
     gnd = []
     for q in range(Q):
-        perm = r.permutation(N)
+        base = np.asarray(Image.open(str(root / 'jpg' / (names[q] + '.jpg'))).convert('RGB')).astype(np.float32)
         h, w = sizes[q]
-        gnd.append({'bbx': [4, 6, w - 5, h - 3], 'easy': sorted(perm[:3].tolist()),
-                    'hard': sorted(perm[3:6].tolist()), 'junk': sorted(perm[6:8].tolist())})
+        easy = [3 + 3 * q, 4 + 3 * q]
+        hard = [5 + 3 * q]
+        for j, sigma in zip(easy + hard, (4.0, 8.0, 25.0)):
+            noisy = np.clip(base + sigma * r.standard_normal(base.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(noisy).save(str(root / 'jpg' / (names[j] + '.jpg')), quality=95)
+            sizes[j] = (h, w)
+        gnd.append({'bbx': [4, 6, w - 5, h - 3], 'easy': easy, 'hard': hard, 'junk': [q]})
     with open(str(root / 'gnd_roxford5k.pkl'), 'wb') as f:
         pickle.dump({'imlist': names, 'qimlist': names[:Q], 'gnd': gnd}, f)
     monkeypatch.setenv('DB_ROOT', str(tmp_path))
     sd = O.synth_state_dict('resnet18', seed=7, gemp=3.0)
-    pca = fitted_pca()
+    files = [str(root / 'jpg' / (n + '.jpg')) for n in names]
+    bd = oracle_descriptors(sd, 'resnet18', files).numpy()
+    qd = oracle_descriptors(sd, 'resnet18', files[:Q], [tuple(g['bbx']) for g in gnd]).numpy()
+    # whitening learned on the descriptor distribution itself (as Landmarks_clean is for the real
+    # models): a PCA unrelated to the data would turn the ranking into noise amplification
+    from sklearn.decomposition import PCA
+    pca = PCA(n_components=8, whiten=True).fit(bd)
     ck = str(tmp_path / 'synth.pt')
     make_checkpoint(ck, 'resnet18', sd, pca)
     js = str(tmp_path / 'res' / 'out.json')
     res = td.main(['--dataset', 'ROxford5K', '--checkpoint', ck, '--gpu', '0', '--threads', '2',
                    '--whiten', 'Landmarks_clean', '--whitenp', '0.25', '--out-json', js, '--detailed'])
-    files = [str(root / 'jpg' / (n + '.jpg')) for n in names]
-    bd = oracle_descriptors(sd, 'resnet18', files).numpy()
-    qd = oracle_descriptors(sd, 'resnet18', files[:Q], [tuple(g['bbx']) for g in gnd]).numpy()
     P = O.PCAParams(pca.mean_, pca.components_, pca.explained_variance_, True)
     scores = O.matmul(O.whiten_features(qd, P, whitenp=0.25), O.whiten_features(bd, P, whitenp=0.25))
     ref = O.mean_ap(scores, gnd)
