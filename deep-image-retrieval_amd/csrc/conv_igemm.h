@@ -27,7 +27,7 @@ typedef hipError_t (*ConvLaunchFn)(const ConvArgs&, hipStream_t);
 
 struct ConvVariant {
     const char* name;
-    int BM, BN, threads, stages;
+    int BM, BN, threads, stages, BK;
     ConvLaunchFn launch[2];    // [dtype]
     ConvLaunchFn launch16[2];  // Cin == 16 stem instantiation, or nullptr
 };

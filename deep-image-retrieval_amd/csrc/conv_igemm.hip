@@ -45,20 +45,24 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shr) {
     return mul ? (__umulhi(n, mul) >> shr) : n;  // mul == 0 encodes division by 1
 }
 
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, bool CIN16>
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvArgs a) {
     static_assert(NST >= 2 && NST <= 4, "ring depth");
+    static_assert((BK == 64 || BK == 32) && (!CIN16 || BK == 64), "K-step");
+    constexpr int RB = BK * 2;    // bytes per LDS row (one pixel / one output channel, BK channels)
+    constexpr int CPR = BK / 8;   // 16-byte chunks per row
+    constexpr int KS = BK / 16;   // MFMA k-substeps per stage
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TM = BM / WGM / 32;  // pixel (B-operand) tiles per wave
     constexpr int TN = BN / WGN / 32;  // channel (A-operand) tiles per wave
-    constexpr int NA = BM * 8 / NT;    // 16-byte X chunks per lane per stage
-    constexpr int NB = BN * 8 / NT;    // 16-byte W chunks per lane per stage
+    constexpr int NA = BM * CPR / NT;  // 16-byte X chunks per lane per stage
+    constexpr int NB = BN * CPR / NT;  // 16-byte W chunks per lane per stage
     constexpr int LPS = NA + NB;       // DMA instructions per lane per stage
     static_assert(TM >= 1 && TN >= 1, "wave tile");
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "chunk split");
-    static_assert((NT / 8) % 16 == 0, "swizzle term must be constant per lane");
-    constexpr int XS = BM * 128;  // bytes of the X tile of one stage
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(NA >= 1 && NB >= 1 && (BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "chunk split");
+    static_assert((NT / CPR) % 16 == 0, "swizzle term must be constant per lane");
+    constexpr int XS = BM * RB;  // bytes of the X tile of one stage
+    constexpr int STAGE_BYTES = (BM + BN) * RB;
     constexpr int EROW = TN * 128 + 16;  // epilogue: one pixel row of TN*32 fp32 + pad
     typedef typename DT::frag_t frag_t;
 
@@ -82,13 +86,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
     // ---- per-lane source offsets (constant over the K loop) --------------------------------------
-    const int srcchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    // chunk slot `tid % CPR` of LDS row `tid / CPR (+ i*NT/CPR)` holds source chunk slot ^ swz(row):
+    // swz = (row >> 1) & 7 for 128-byte rows, (row >> 2) & 3 for 64-byte rows (one 256-byte bank row
+    // holds 2 resp. 4 LDS rows) - both reduce to bits of tid because NT/CPR is a multiple of 16.
+    const int srcchunk = (tid & (CPR - 1)) ^ ((tid >> 4) & (CPR - 1));
     const bool one_tap = (a.R * a.S == 1);  // 1x1: no padding, K advances through the scalar offset
     int xbase[NA];       // byte offset of tap (0,0), channel chunk `srcchunk` (may be negative)
     uint32_t xmask[NA];  // bit per tap (stem: per filter row): tap inside the image and row valid
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = i * (NT / 8) + (tid >> 3);
+        const int row = i * (NT / CPR) + tid / CPR;
         const int m = tile_m * BM + row;
         const bool mvalid = m < a.M;
         if (a.flat) {  // 1x1, stride 1: output pixel m reads input pixel m
@@ -103,20 +110,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
             const int ih0 = (int)oh * a.stride - a.pad;
             const int iw0 = (int)ow * a.stride - a.pad;
             xbase[i] = (((int)b * a.H + ih0) * a.W + iw0) * a.Cin * 2 + srcchunk * 16;
-            // validity bits: rows r with 0 <= ih0+r < H, columns s with 0 <= iw0+s < W
-            uint32_t rbits = 0, cbits = 0;
-            for (int r = 0; r < a.R; ++r)
-                if ((unsigned)(ih0 + r) < (unsigned)a.H) rbits |= 1u << r;
+            // validity bits in closed form (R, S <= 4): rows r in [max(0,-ih0), min(R, H-ih0)),
+            // columns s in [max(0,-iw0), min(S, W-iw0))
+            auto range_bits = [](int lo, int hi) -> uint32_t {
+                return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+            };
+            const int R_ = CIN16 ? 4 : a.R;
+            const uint32_t rbits = range_bits(max(0, -ih0), min(R_, a.H - ih0));
             if (CIN16) {
                 // one K-step per filter row; this lane's chunk is pixel (srcchunk >> 1) of the row
                 const bool wok = (unsigned)(iw0 + (srcchunk >> 1)) < (unsigned)a.W;
                 xmask[i] = (mvalid && wok) ? rbits : 0u;
             } else {
-                for (int s = 0; s < a.S; ++s)
-                    if ((unsigned)(iw0 + s) < (unsigned)a.W) cbits |= 1u << s;
+                const uint32_t cbits = range_bits(max(0, -iw0), min(a.S, a.W - iw0));
                 uint32_t mask = 0;
-                for (int r = 0; r < a.R; ++r)
-                    if ((rbits >> r) & 1u) mask |= cbits << (r * a.S);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mask |= ((rbits >> r) & 1u) ? (cbits << (r * a.S)) : 0u;
                 xmask[i] = mvalid ? mask : 0u;
             }
         }
@@ -127,7 +136,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     uint32_t wvoff[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = i * (NT / 8) + (tid >> 3);
+        const int row = i * (NT / CPR) + tid / CPR;
         wvoff[i] = (uint32_t)(((tile_n * BN + row) * a.Ktot + srcchunk * 8) * 2);
     }
 
@@ -145,16 +154,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            dma16(rsrc_w, stage + XS + (i * NT + wave * 64) * 16, wvoff[i], t * 128);
+            dma16(rsrc_w, stage + XS + (i * NT + wave * 64) * 16, wvoff[i], t * RB);
     };
 
     // ---- fragment read offsets -----------------------------------------------------------------
-    const int lswz = (lane >> 1) & 7;
-    int loff[4];
+    const int lswz = BK == 64 ? ((lane >> 1) & 7) : ((lane >> 2) & 3);
+    int loff[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) loff[ks] = lrow * 128 + (((2 * ks + lhi) ^ lswz) << 4);
-    const int xfrag = (wm * TM * 32) * 128;
-    const int wfrag = XS + (wn * TN * 32) * 128;
+    for (int ks = 0; ks < KS; ++ks) loff[ks] = lrow * RB + (((2 * ks + lhi) ^ lswz) << 4);
+    const int xfrag = (wm * TM * 32) * RB;
+    const int wfrag = XS + (wn * TN * 32) * RB;
 
     // ---- accumulators start at the bias of their 4 consecutive channels -----------------------
     f32x16_t acc[TN][TM];
@@ -172,14 +181,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 
     auto compute = [&](const char* stage) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             frag_t wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                wf[i] = *(const frag_t*)(stage + wfrag + i * 4096 + loff[ks]);
+                wf[i] = *(const frag_t*)(stage + wfrag + i * 32 * RB + loff[ks]);
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                xf[j] = *(const frag_t*)(stage + xfrag + j * 4096 + loff[ks]);
+                xf[j] = *(const frag_t*)(stage + xfrag + j * 32 * RB + loff[ks]);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -214,10 +223,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     // passing it means (a) stage t has landed for every wave (each waited on its own counted vmcnt
     // first), (b) every wave has finished reading slot (t-1) % NST, the slot refilled right after.
     const int T = a.T;
-    const int cpb = CIN16 ? 1 : (a.Cin >> 6);  // K-steps per filter tap
+    const int cpb = CIN16 ? 1 : (a.Cin / BK);  // K-steps per filter tap
     int tap = 0, cc = 0, r = 0, s = 0;         // state of the step being ISSUED
     auto koff_now = [&]() {                    // bytes
-        return CIN16 ? (r * a.W * 32) : (((r * a.W + s) * a.Cin + cc * 64) * 2);
+        return CIN16 ? (r * a.W * 32) : (((r * a.W + s) * a.Cin + cc * BK) * 2);
     };
     auto advance = [&]() {
         if (++cc == cpb) {
@@ -331,16 +340,16 @@ static void fastdiv_init(uint32_t d, uint32_t& mul, uint32_t& shr) {
     shr = p - 32;
 }
 
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, bool CIN16>
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16>
 static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TN = BN / WGN / 32;
     constexpr int EROW = TN * 128 + 16;
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int EPI_BYTES = (NT / 64) * 32 * EROW;
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, CIN16>;
+    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -349,6 +358,7 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     ConvArgs b = a;
+    b.T = a.Ktot / BK;
     b.tiles_m = ceil_div(a.M, BM);
     b.tiles_n = a.Cout / BN;
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
@@ -357,42 +367,45 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     fastdiv_init((uint32_t)(a.OH * a.OW), b.div_ohw_mul, b.div_ohw_shr);
     fastdiv_init((uint32_t)a.OW, b.div_ow_mul, b.div_ow_shr);
     // a short K loop never touches the far slots of the ring: ask for less LDS, more residency
-    const int used = (a.T < NST ? a.T : NST) * STAGE_BYTES;
+    const int used = (b.T < NST ? b.T : NST) * STAGE_BYTES;
     const int lds = used > EPI_BYTES ? used : EPI_BYTES;
     hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(NT), lds, stream, b);
     return hipGetLastError();
 }
 
-#define DIR_VARIANT(BM, BN, WGM, WGN, NST, NAME)                                             \
-    {NAME, BM, BN, 64 * WGM * WGN, NST,                                                      \
-     {launch_variant<BF16, BM, BN, WGM, WGN, NST, false>,                                    \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, false>},                                   \
+#define DIR_VARIANT(BM, BN, WGM, WGN, NST, BK, NAME)                                         \
+    {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
      {nullptr, nullptr}}
 // BN == 64 variants also carry the Cin == 16 (space-to-depth stem) instantiation.
 #define DIR_VARIANT16(BM, BN, WGM, WGN, NST, NAME)                                           \
-    {NAME, BM, BN, 64 * WGM * WGN, NST,                                                      \
-     {launch_variant<BF16, BM, BN, WGM, WGN, NST, false>,                                    \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, false>},                                   \
-     {launch_variant<BF16, BM, BN, WGM, WGN, NST, true>,                                     \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, true>}}
+    {NAME, BM, BN, 64 * WGM * WGN, NST, 64,                                                  \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, false>,                                \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, false>},                               \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, true>,                                 \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}}
 
-// name = <pixels>x<channels>_w<waves m>x<waves n>[_s<ring depth>]
+// name = <pixels>x<channels>_w<waves m>x<waves n>[_s<ring depth>][_k<K-step>]
 static const ConvVariant kVariants[] = {
-    DIR_VARIANT(128, 128, 2, 2, 2, "128x128_w2x2"),
+    DIR_VARIANT(128, 128, 2, 2, 2, 64, "128x128_w2x2"),
     DIR_VARIANT16(128, 64, 2, 2, 2, "128x64_w2x2"),
     DIR_VARIANT16(256, 64, 4, 1, 2, "256x64_w4x1"),
-    DIR_VARIANT(256, 128, 4, 2, 2, "256x128_w4x2"),
-    DIR_VARIANT(128, 256, 2, 4, 2, "128x256_w2x4"),
-    DIR_VARIANT(256, 256, 4, 2, 2, "256x256_w4x2"),
-    DIR_VARIANT(64, 128, 2, 2, 2, "64x128_w2x2"),
+    DIR_VARIANT(256, 128, 4, 2, 2, 64, "256x128_w4x2"),
+    DIR_VARIANT(128, 256, 2, 4, 2, 64, "128x256_w2x4"),
+    DIR_VARIANT(256, 256, 4, 2, 2, 64, "256x256_w4x2"),
+    DIR_VARIANT(64, 128, 2, 2, 2, 64, "64x128_w2x2"),
     DIR_VARIANT16(64, 64, 2, 1, 2, "64x64_w2x1"),
-    DIR_VARIANT(64, 128, 2, 2, 4, "64x128_w2x2_s4"),
-    DIR_VARIANT(128, 128, 2, 2, 3, "128x128_w2x2_s3"),
+    DIR_VARIANT(64, 128, 2, 2, 4, 64, "64x128_w2x2_s4"),
+    DIR_VARIANT(128, 128, 2, 2, 3, 64, "128x128_w2x2_s3"),
     DIR_VARIANT16(128, 64, 2, 2, 4, "128x64_w2x2_s4"),
-    DIR_VARIANT16(64, 64, 2, 1, 4, "64x64_w2x1_s4"),
-    DIR_VARIANT(256, 128, 4, 2, 3, "256x128_w4x2_s3"),
-    DIR_VARIANT(128, 256, 2, 4, 3, "128x256_w2x4_s3"),
+    DIR_VARIANT(256, 128, 4, 2, 3, 64, "256x128_w4x2_s3"),
+    DIR_VARIANT(128, 256, 2, 4, 3, 64, "128x256_w2x4_s3"),
     DIR_VARIANT16(256, 64, 4, 1, 3, "256x64_w4x1_s3"),
+    DIR_VARIANT(256, 256, 4, 2, 4, 32, "256x256_w4x2_s4_k32"),
+    DIR_VARIANT(256, 256, 4, 2, 3, 32, "256x256_w4x2_s3_k32"),
+    DIR_VARIANT(256, 128, 4, 2, 4, 32, "256x128_w4x2_s4_k32"),
+    DIR_VARIANT(128, 128, 2, 2, 4, 32, "128x128_w2x2_s4_k32"),
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -409,7 +422,9 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
 
 static int find_variant(int BM, int BN, int nst) {
     for (int v = 0; v < kNumVariants; ++v)
-        if (kVariants[v].BM == BM && kVariants[v].BN == BN && kVariants[v].stages == nst) return v;
+        if (kVariants[v].BM == BM && kVariants[v].BN == BN && kVariants[v].stages == nst &&
+            kVariants[v].BK == 64)
+            return v;
     return -1;
 }
 
@@ -438,7 +453,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     } else if (a.Cin % 64 != 0) {
         return fail(DIR_ERR_INVALID, "conv: Cin must be a multiple of 64 (or 16 for the stem)");
     }
-    if (a.R * a.S > 16) return fail(DIR_ERR_INVALID, "conv: at most 16 filter taps");
+    if (a.R > 4 || a.S > 4) return fail(DIR_ERR_INVALID, "conv: filter larger than 4x4");
     if ((long)a.B * a.H * a.W * a.Cin >= (1L << 30) || (long)a.M * a.Cout >= (1L << 30) ||
         (long)a.Cout * a.Ktot >= (1L << 30))
         return fail(DIR_ERR_INVALID, "conv: tensor exceeds 2^31 bytes; lower the batch");
