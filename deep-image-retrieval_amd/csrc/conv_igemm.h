@@ -30,7 +30,11 @@ struct ConvVariant {
     int BM, BN, threads, stages, BK;
     ConvLaunchFn launch[2];    // [dtype]
     ConvLaunchFn launch16[2];  // Cin == 16 stem instantiation, or nullptr
+    int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip)
 };
+
+bool conv_patch3x3_admissible(const ConvArgs& a);
+hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 
 int conv_variant_count();
 const ConvVariant& conv_variant(int i);

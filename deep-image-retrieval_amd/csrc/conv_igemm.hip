@@ -377,14 +377,14 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
-     {nullptr, nullptr}}
+     {nullptr, nullptr}, 0}
 // BN == 64 variants also carry the Cin == 16 (space-to-depth stem) instantiation.
 #define DIR_VARIANT16(BM, BN, WGM, WGN, NST, NAME)                                           \
     {NAME, BM, BN, 64 * WGM * WGN, NST, 64,                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, false>},                               \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, true>,                                 \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}}
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}, 0}
 
 // name = <pixels>x<channels>_w<waves m>x<waves n>[_s<ring depth>][_k<K-step>]
 static const ConvVariant kVariants[] = {
@@ -406,6 +406,9 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT(256, 256, 4, 2, 3, 32, "256x256_w4x2_s3_k32"),
     DIR_VARIANT(256, 128, 4, 2, 4, 32, "256x128_w4x2_s4_k32"),
     DIR_VARIANT(128, 128, 2, 2, 4, 32, "128x128_w2x2_s4_k32"),
+    // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
+    {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
+    {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -415,6 +418,7 @@ const ConvVariant& conv_variant(int i) { return kVariants[i]; }
 bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const ConvVariant& cv = kVariants[v];
+    if (cv.kind == 1) return a.Cout == cv.BN && conv_patch3x3_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
@@ -423,7 +427,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
 static int find_variant(int BM, int BN, int nst) {
     for (int v = 0; v < kNumVariants; ++v)
         if (kVariants[v].BM == BM && kVariants[v].BN == BN && kVariants[v].stages == nst &&
-            kVariants[v].BK == 64)
+            kVariants[v].BK == 64 && kVariants[v].kind == 0)
             return v;
     return -1;
 }
@@ -465,7 +469,8 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (!conv_variant_admissible(variant, a))
         return fail(DIR_ERR_INVALID, "conv: variant not admissible for this shape");
     const ConvVariant& cv = kVariants[variant];
-    hipError_t e = (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
+    hipError_t e = cv.kind == 1 ? conv_patch3x3_launch(a, dtype, stream)
+                                : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)
         return fail(DIR_ERR_HIP, std::string("conv launch ") + cv.name + ": " + hipGetErrorString(e));
     return DIR_OK;

@@ -27,12 +27,21 @@ def _variants():
         from dirtorch_amd import _lib
         return list(range(_lib.load().dir_conv_variant_count()))
     except Exception:
-        return list(range(12))
+        return list(range(20))
 
 
 def _rand(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
+
+
+def variant_admissible(name, Cin, Cout, k, stride, pad):
+    """Mirror of conv_variant_admissible (csrc/conv_igemm.hip): igemm variants need BN | Cout; the
+    LDS-patch variants are 3x3 stride-1 pad-1 with Cin == Cout == BN."""
+    bn = int(name.split('_')[0].split('x')[1])
+    if 'patch3x3' in name:
+        return k == 3 and stride == 1 and pad == 1 and Cin == Cout == bn
+    return Cout % bn == 0
 
 
 def conv_reference(x_nhwc16, w16, bias, res16, stride, pad, relu):
@@ -76,6 +85,8 @@ CONV_SHAPES = [
     ('3x3_s2', 2, 15, 14, 128, 128, 3, 2, 1, False, True),
     ('1x1_s2_ds', 2, 14, 13, 256, 512, 1, 2, 0, False, False),
     ('3x3_multi_tile', 4, 20, 20, 64, 128, 3, 1, 1, True, True),
+    ('3x3_patch64_ragged', 2, 13, 37, 64, 64, 3, 1, 1, True, True),
+    ('3x3_patch128_exact', 1, 16, 64, 128, 128, 3, 1, 1, False, False),
 ]
 
 
@@ -88,9 +99,8 @@ def test_conv_variant_vs_oracle(shape, variant, dname):
     names = ops.conv_variant_names()
     if variant >= len(names):
         pytest.skip('no such variant')
-    bn = int(names[variant].split('_')[0].split('x')[1])
-    if Cout % bn != 0:
-        pytest.skip('variant %s not admissible for Cout=%d' % (names[variant], Cout))
+    if not variant_admissible(names[variant], Cin, Cout, k, stride, pad):
+        pytest.skip('variant %s not admissible for this shape' % names[variant])
     dt = DTYPES[dname]
     x = _rand((B, H, W, Cin), 1).to(dt)
     w = _rand((Cout, k, k, Cin), 2, (2.0 / (k * k * Cin)) ** 0.5).to(dt)
@@ -138,7 +148,7 @@ def test_stem_space_to_depth_vs_7x7(hw, dname):
     np.testing.assert_array_equal(s[0, 3, 2, 0:3].numpy(), img.to(dt).float()[0, :, 6, 4].numpy())
     np.testing.assert_array_equal(s[1, 1, 5, 9:12].numpy(), img.to(dt).float()[1, :, 3, 11].numpy())
     wp = ops.pack_stem_weight(w7, dt).cuda()
-    for variant in [v for v, n in enumerate(ops.conv_variant_names()) if 'x64_' in n]:
+    for variant in [v for v, n in enumerate(ops.conv_variant_names()) if 'x64_' in n and 'patch' not in n]:
         y = ops.conv_bn_act(s2d, wp, bias.cuda(), None, stride=1, pad=2, relu=True, out_hw=(OH, OW),
                             variant=variant)
         check_close(y, ref, dname, 'stem %dx%d variant %d' % (H, W, variant))
@@ -296,6 +306,7 @@ BIG_SHAPES = [  # ResNet-101 @ 1024x1024 layer shapes (B = 1): name, H, W, Cin, 
     ('layer1.conv2', 256, 256, 64, 64, 3, 1, 1, False),
     ('layer1.conv3', 256, 256, 64, 256, 1, 1, 0, True),
     ('layer2.0.conv2_s2', 256, 256, 128, 128, 3, 2, 1, False),
+    ('layer2.1.conv2', 128, 128, 128, 128, 3, 1, 1, False),
     ('layer3.conv1', 64, 64, 1024, 256, 1, 1, 0, False),
     ('layer3.conv2', 64, 64, 256, 256, 3, 1, 1, False),
     ('layer4.0.downsample', 64, 64, 1024, 2048, 1, 2, 0, False),
@@ -317,7 +328,7 @@ def test_conv_full_size_vs_device_checker(shape):
     ref = ops.conv_bn_act(x, w, bias, res, stride=stride, pad=pad, relu=True, naive=True).float()
     names = ops.conv_variant_names()
     for v, n in enumerate(names):
-        if Cout % int(n.split('_')[0].split('x')[1]) != 0:
+        if not variant_admissible(n, Cin, Cout, k, stride, pad):
             continue
         y = ops.conv_bn_act(x, w, bias, res, stride=stride, pad=pad, relu=True, variant=v).float()
         err = (y - ref).abs()
