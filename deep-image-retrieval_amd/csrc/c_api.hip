@@ -283,6 +283,15 @@ int dir_prep_input(const void* img, int fmt, const float* mean3, const float* st
     DIR_CATCH
 }
 
+int dir_stem_pool(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
+                  int OH, int OW, int dtype, void* stream) {
+    DIR_TRY
+    if (!s2d || !w || !bias || !y || B <= 0 || H2 <= 0 || W2 <= 0 || OH <= 0 || OW <= 0)
+        return fail(DIR_ERR_INVALID, "stem_pool: bad argument");
+    return stem_pool_launch(s2d, w, bias, y, B, H2, W2, OH, OW, dtype, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     DIR_TRY
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(DIR_ERR_INVALID, "maxpool: bad argument");

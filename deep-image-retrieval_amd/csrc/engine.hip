@@ -402,15 +402,27 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
                            s2d, n, dtype);
         DIR_HIP_CHECK(hipGetLastError());
     }
-    // 2. stem + maxpool
-    rc = run_conv(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
-    if (rc != DIR_OK) return rc;
-    rc = prof_begin("maxpool", "maxpool_3x3s2", 0,
-                    2.0 * ((double)B * p.OH1 * p.OW1 * 64 + (double)B * p.PH * p.PW * 64), stream);
-    if (rc != DIR_OK) return rc;
-    rc = maxpool_3x3s2(stem, cur, B, p.OH1, p.OW1, 64, dtype, stream);
-    if (rc != DIR_OK) return rc;
-    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    // 2. stem + maxpool: one kernel (stem_pool.hip) unless DIRTORCH_AMD_UNFUSED_STEM=1
+    static const bool unfused_stem = getenv("DIRTORCH_AMD_UNFUSED_STEM") != nullptr;
+    if (unfused_stem) {
+        rc = run_conv(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
+        if (rc != DIR_OK) return rc;
+        rc = prof_begin("maxpool", "maxpool_3x3s2", 0,
+                        2.0 * ((double)B * p.OH1 * p.OW1 * 64 + (double)B * p.PH * p.PW * 64), stream);
+        if (rc != DIR_OK) return rc;
+        rc = maxpool_3x3s2(stem, cur, B, p.OH1, p.OW1, 64, dtype, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    } else {
+        rc = prof_begin("conv1+maxpool", "stem_pool", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
+                        2.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256),
+                        stream);
+        if (rc != DIR_OK) return rc;
+        rc = stem_pool_launch(s2d, convs[0].d_w, convs[0].d_bias, cur, B, p.H2, p.W2, p.OH1, p.OW1,
+                              dtype, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    }
 
     // 3. residual stages
     int h = p.PH, w = p.PW;

@@ -12,6 +12,8 @@ int global_pool(const void* x, float* out, int B, int H, int W, int C, int pooli
 int l2norm_rows(float* x, int rows, int cols, float eps, hipStream_t stream);
 int multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                     hipStream_t stream);
+int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
+                     int OH, int OW, int dtype, hipStream_t stream);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
 int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,

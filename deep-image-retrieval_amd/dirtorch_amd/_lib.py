@@ -64,6 +64,8 @@ SIGNATURES = {
                               + [c_int] * 13 + [c_void_p]),
     'dir_prep_input': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p,
                                c_int, c_int, c_int, c_int, c_void_p]),
+    'dir_stem_pool': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_void_p]),
     'dir_maxpool_3x3s2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dir_global_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 c_float, c_float, c_int, c_void_p]),

@@ -169,3 +169,15 @@ def rank_counts(scores, probe_idx):
     pscores = torch.zeros(Q, P, dtype=torch.float32, device=scores.device)
     call('dir_rank_counts', ptr(scores), N, Q, N, ptr(probe_idx), P, ptr(counts), ptr(pscores), stream_ptr())
     return counts, pscores
+
+
+def stem_pool(s2d, w_packed, bias, out_hw):
+    """Fused stem: s2d image [B,H2,W2,16] + packed 4x4x16 filter -> pooled [B,PH,PW,64];
+    out_hw = (OH, OW) of the 7x7 s2 convolution."""
+    _need_cuda(s2d, w_packed, bias)
+    B, H2, W2, _ = s2d.shape
+    OH, OW = out_hw
+    y = torch.empty(B, (OH - 1) // 2 + 1, (OW - 1) // 2 + 1, 64, dtype=s2d.dtype, device=s2d.device)
+    call('dir_stem_pool', ptr(s2d), ptr(w_packed), ptr(bias), ptr(y), B, H2, W2, OH, OW,
+         _dtype_code(s2d), stream_ptr())
+    return y

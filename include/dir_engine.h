@@ -141,6 +141,12 @@ int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const
 /* Image -> space-to-depth stem input [B, ceil(H/2), ceil(W/2), 16] 16-bit (12 used channels). */
 int dir_prep_input(const void* img, int img_format, const float* mean3, const float* std3,
                    void* out, int B, int H, int W, int dtype, void* stream);
+/* K1+K2+K3 fused: the whole stem (conv 7x7 s2 + BN + ReLU + MaxPool 3x3 s2,
+ * dirtorch/nets/backbones/resnet.py:115-119) from the space-to-depth image of dir_prep_input
+ * [B,H2,W2,16] and the 4x4x16 packed stem filter to the pooled map [B,PH,PW,64]; OH x OW is the conv
+ * output size the pool runs over.  What dir_forward uses. */
+int dir_stem_pool(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
+                  int OH, int OW, int dtype, void* stream);
 /* K3: MaxPool2d(3, stride 2, pad 1) on NHWC (dirtorch/nets/backbones/resnet.py:119). */
 int dir_maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 /* K8: global pooling over H*W of NHWC x -> fp32 [B,C] (dirtorch/nets/layers/pooling.py:38-40);

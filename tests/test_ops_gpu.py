@@ -154,6 +154,30 @@ def test_stem_space_to_depth_vs_7x7(hw, dname):
         check_close(y, ref, dname, 'stem %dx%d variant %d' % (H, W, variant))
 
 
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('hw', [(37, 41), (64, 64), (30, 23), (224, 131), (9, 120)])
+def test_fused_stem_pool_vs_conv_relu_maxpool(hw, dname):
+    """stem_pool == MaxPool2d(3,2,1)(ReLU(Conv2d(3,64,7,2,3)(x) + b)) (resnet.py:158-161)."""
+    ops = _ops()
+    H, W = hw
+    dt = DTYPES[dname]
+    img = _rand((2, 3, H, W), 23)
+    w7 = _rand((64, 3, 7, 7), 24, (2.0 / (49 * 64)) ** 0.5 * 3)
+    bias = _rand((64,), 25, 0.1)
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    conv = F.relu(F.conv2d(img.to(dt).float(), w7.to(dt).float(), bias, 2, 3))
+    # the unfused path rounds the conv output to 16 bits before pooling; max commutes with rounding
+    ref = F.max_pool2d(conv.to(dt).float(), 3, 2, 1).permute(0, 2, 3, 1).contiguous()
+    s2d = ops.prep_input(img.cuda(), dt)
+    y = ops.stem_pool(s2d, ops.pack_stem_weight(w7, dt).cuda(), bias.cuda(), (OH, OW))
+    assert y.shape == ref.shape
+    check_close(y, ref, dname, 'stem_pool %dx%d' % (H, W))
+    # and bit-for-bit against the two-kernel path of this library
+    unf = ops.maxpool_3x3s2(ops.conv_bn_act(s2d, ops.pack_stem_weight(w7, dt).cuda(), bias.cuda(), None,
+                                            stride=1, pad=2, relu=True, out_hw=(OH, OW)))
+    assert torch.equal(unf, y)
+
+
 def test_prep_input_uint8_normalises_like_totensor():
     ops = _ops()
     g = torch.Generator().manual_seed(12)
