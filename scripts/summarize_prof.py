@@ -20,12 +20,15 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d), (?:(\d), )?(\w+)>', name)
+    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', name)
+    if m:   # <DT, BM, BN, WGM, WGN, NST, BK, CIN16> -> the variant names of csrc/conv_igemm.hip
+        dt, bm, bn, wm, wn, nst, bk, c16 = m.groups()
+        return 'conv_igemm<%sx%s_w%sx%s%s%s>%s[%s]' % (bm, bn, wm, wn, '_s' + nst if nst != '2' else '',
+                                                      '_k' + bk if bk != '64' else '',
+                                                      '/stem' if c16 == 'true' else '', dt.lower())
+    m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)>', name)
     if m:
-        dt, bm, bn, wm, wn, stg, nst, c16 = m.groups()
-        return 'conv_igemm<%sx%s_w%sx%s_%s%s>%s[%s]' % (bm, bn, wm, wn, 'glds' if stg == '0' else 'reg',
-                                                       '_s' + nst if nst and nst != '2' else '',
-                                                       '/stem' if c16 == 'true' else '', dt.lower())
+        return 'conv_igemm<256x%s_patch3x3>[%s]' % (m.group(2), m.group(1).lower())
     m = re.search(r'dir::(\w+)', name)
     if m:
         return m.group(1)
