@@ -433,17 +433,33 @@ static int find_variant(int BM, int BN, int nst) {
 }
 
 // Heuristic used when a shape has not been autotuned (variable-size images, the reference's real
-// workload): widest channel tile that divides Cout, pixel tile as large as still leaves >= 2
-// workgroups per CU (256 CUs) so the tail wave stays short.
+// workload).  Distilled from the autotuner's choices on ResNet-101 at 1024^2 (profiles/
+// r01_tuned_variants_b32_1024.txt): narrow 3x3 layers take the LDS-patch kernel; K = 64 layers the
+// long 256x64 tile; wide outputs with a real K loop the 256x256 tile; everything else 128x128 - each
+// falling back to smaller pixel tiles until about three quarters of the 256 CUs get a workgroup.
 int conv_pick_variant(const ConvArgs& a) {
-    const int bn = (a.Cout % 128 == 0) ? 128 : 64;
-    const int bms[3] = {256, 128, 64};
+    for (int v = 0; v < kNumVariants; ++v)
+        if (kVariants[v].kind == 1 && a.Cin == 64 && conv_variant_admissible(v, a)) return v;
+    const int T = a.Ktot / 64;
+    int bm[3], bn[3], n = 0;
+    auto add = [&](int m, int c) {
+        bm[n] = m;
+        bn[n] = c;
+        ++n;
+    };
+    if (T <= 1 || a.Cout % 128 != 0) {
+        add(256, 64), add(128, 64), add(64, 64);
+    } else if (a.Cout % 256 == 0 && T >= 3) {
+        add(256, 256), add(128, 128), add(64, 128);
+    } else {
+        add(128, 128), add(64, 128);
+    }
     int last = -1;
-    for (int i = 0; i < 3; ++i) {
-        const int v = find_variant(bms[i], bn, 2);
+    for (int i = 0; i < n; ++i) {
+        const int v = find_variant(bm[i], bn[i], 2);
         if (v < 0 || !conv_variant_admissible(v, a)) continue;
         last = v;
-        if ((long)ceil_div(a.M, bms[i]) * (a.Cout / bn) >= 512) return v;
+        if ((long)ceil_div(a.M, bm[i]) * (a.Cout / bn[i]) >= 192) return v;
     }
     return last;
 }

@@ -100,16 +100,26 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
     };
 
     const int T = (K + 31) / 32;
+    // Every workgroup walks K from a different starting slab (a rotation of the same sum).  With a
+    // power-of-two row pitch (D = 2048 floats = 8 KiB) workgroups marching through K in lock-step
+    // would all be fetching addresses congruent modulo the pitch - the same few HBM channels - at
+    // any instant; staggering the phase spreads the stream over all of them.
+    const int rot = (int)(((unsigned)tile_i * 7u + (unsigned)tile_j * 3u) % (unsigned)T);
+    auto slab = [&](int t) {
+        int u = t + rot;
+        if (u >= T) u -= T;
+        return u * 32;
+    };
     char* stage0 = smem;
     char* stage1 = smem + STAGE_BYTES;
-    fetch(0);
+    fetch(slab(0));
     commit(stage0);
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         char* cur = (t & 1) ? stage1 : stage0;
         char* nxt = (t & 1) ? stage0 : stage1;
         const bool more = t + 1 < T;
-        if (more) fetch((t + 1) * 32);
+        if (more) fetch(slab(t + 1));
         compute(cur);
         if (more) commit(nxt);
         __syncthreads();
