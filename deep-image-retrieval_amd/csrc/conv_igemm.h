@@ -30,9 +30,12 @@ struct ConvVariant {
     int BM, BN, threads, stages, BK;
     ConvLaunchFn launch[2];    // [dtype]
     ConvLaunchFn launch16[2];  // Cin == 16 stem instantiation, or nullptr
-    int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip)
+    int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip),
+                               // 2 = persistent 256x256 1x1 (conv_persist.hip)
 };
 
+bool conv1x1_persist_admissible(const ConvArgs& a);
+hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

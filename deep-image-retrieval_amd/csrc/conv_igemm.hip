@@ -409,6 +409,8 @@ static const ConvVariant kVariants[] = {
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
     {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
+    // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
+    {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -419,6 +421,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const ConvVariant& cv = kVariants[v];
     if (cv.kind == 1) return a.Cout == cv.BN && conv_patch3x3_admissible(a);
+    if (cv.kind == 2) return conv1x1_persist_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
@@ -485,8 +488,9 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (!conv_variant_admissible(variant, a))
         return fail(DIR_ERR_INVALID, "conv: variant not admissible for this shape");
     const ConvVariant& cv = kVariants[variant];
-    hipError_t e = cv.kind == 1 ? conv_patch3x3_launch(a, dtype, stream)
-                                : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
+    hipError_t e = cv.kind == 1   ? conv_patch3x3_launch(a, dtype, stream)
+                   : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
+                                  : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)
         return fail(DIR_ERR_HIP, std::string("conv launch ") + cv.name + ": " + hipGetErrorString(e));
     return DIR_OK;

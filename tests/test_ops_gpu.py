@@ -41,6 +41,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad):
     bn = int(name.split('_')[0].split('x')[1])
     if 'patch3x3' in name:
         return k == 3 and stride == 1 and pad == 1 and Cin == Cout == bn
+    if 'persist1x1' in name:
+        return k == 1 and pad == 0 and Cout % 256 == 0 and Cin >= 128
     return Cout % bn == 0
 
 
@@ -86,6 +88,8 @@ CONV_SHAPES = [
     ('1x1_s2_ds', 2, 14, 13, 256, 512, 1, 2, 0, False, False),
     ('3x3_multi_tile', 4, 20, 20, 64, 128, 3, 1, 1, True, True),
     ('3x3_patch64_ragged', 2, 13, 37, 64, 64, 3, 1, 1, True, True),
+    ('1x1_persist_flat', 2, 24, 27, 256, 512, 1, 1, 0, True, True),
+    ('1x1_persist_k128', 1, 40, 40, 128, 256, 1, 1, 0, False, True),
     ('3x3_patch128_exact', 1, 16, 64, 128, 128, 3, 1, 1, False, False),
 ]
 
