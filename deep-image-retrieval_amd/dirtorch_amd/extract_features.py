@@ -21,40 +21,38 @@ from .utils.convenient import mkdir
 
 def extract_features(db, net, trfs, pooling='mean', gemp=3, detailed=False, whiten=None,
                      threads=8, batch_size=16, output=None, dbg=()):
-    """Extract (pool, whiten) descriptors of a dataset and save them as .npy."""
+    """Descriptors of `db` (pooled over the transform chains, L2-normalised, optionally whitened)
+    saved as .npy: one file, or <output>.qdescs / .dbdescs when the dataset has its own query set."""
     print("\n>> Extracting features...")
     try:
         query_db = db.get_query_db()
     except NotImplementedError:
         query_db = None
+    separate_queries = query_db is not None and query_db is not db
 
-    bdescs, qdescs = [], []
-    trfs_list = [trfs] if isinstance(trfs, str) else trfs
-    for trfs in trfs_list:
+    per_scale = {'db': [], 'q': []}
+    for chain in ([trfs] if isinstance(trfs, str) else trfs):
         kw = dict(iscuda=net.iscuda, threads=threads, batch_size=batch_size,
-                  same_size='Pad' in trfs or 'Crop' in trfs)
-        bdescs.append(ddist.extract_sharded(test.extract_image_features, db, trfs, net, desc="DB", **kw))
-        if query_db is not None:
-            qdescs.append(bdescs[-1] if db is query_db
-                          else test.extract_image_features(query_db, trfs, net, desc="query", **kw))
+                  same_size='Pad' in chain or 'Crop' in chain)
+        per_scale['db'].append(ddist.extract_sharded(test.extract_image_features, db, chain, net, desc="DB", **kw))
+        if separate_queries:
+            per_scale['q'].append(test.extract_image_features(query_db, chain, net, desc="query", **kw))
 
-    bdescs = tonumpy(common.l2_normalize(pool(bdescs, pooling, gemp)))
-    if query_db is not None:
-        qdescs = tonumpy(common.l2_normalize(pool(qdescs, pooling, gemp)))
+    def finish(descs):
+        descs = tonumpy(common.l2_normalize(pool(descs, pooling, gemp)))
+        return common.whiten_features(descs, net.pca, **whiten) if whiten is not None else descs
 
-    if whiten is not None:
-        bdescs = common.whiten_features(bdescs, net.pca, **whiten)
-        if query_db is not None:
-            qdescs = common.whiten_features(qdescs, net.pca, **whiten)
+    bdescs = finish(per_scale['db'])
+    qdescs = finish(per_scale['q']) if separate_queries else None
 
     if ddist.rank() == 0:
         mkdir(output, isfile=True)
-        if query_db is db or query_db is None:
-            np.save(output, bdescs)
+        if separate_queries:
+            stem, ext = osp.splitext(output)
+            np.save(stem + '.qdescs' + ext, qdescs)
+            np.save(stem + '.dbdescs' + ext, bdescs)
         else:
-            o = osp.splitext(output)
-            np.save(o[0] + '.qdescs' + o[1], qdescs)
-            np.save(o[0] + '.dbdescs' + o[1], bdescs)
+            np.save(output, bdescs)
         print('Features extracted.')
     return bdescs
 
@@ -63,27 +61,20 @@ load_model = test.load_model
 
 
 def main(argv=None):
-    parser = test.build_parser('Extract features')
-    parser.add_argument('--output', type=str, default="", help='path to output features')
-    parser.add_argument('--gpu', type=int, nargs='+', help='GPU ids')
-    parser.add_argument('--whiten', type=str, default=None, help='applies whitening')
-    parser.add_argument('--whitenp', type=float, default=0.5, help='whitening power, default is 0.5 (i.e., the sqrt)')
-    args = parser.parse_args(argv)
-    args.iscuda = test.setup_devices(args.gpu)
-
+    args = test.build_parser('Extract features', extra=[
+        (('--output',), dict(type=str, default='', help='path to output features')),
+        (('--gpu',), dict(type=int, nargs='+', help='GPU ids')),
+        (('--whiten',), dict(type=str, default=None, help='applies whitening')),
+        (('--whitenp',), dict(type=float, default=0.5, help='whitening power, default is 0.5 (i.e., the sqrt)')),
+    ]).parse_args(argv)
+    iscuda = test.setup_devices(args.gpu)
     dataset = datasets.create(args.dataset)
     print("Dataset:", dataset)
-
-    net = load_model(args.checkpoint, args.iscuda)
-    if args.whiten:
-        net.pca = net.pca[args.whiten]
-        args.whiten = {'whitenp': args.whitenp, 'whitenv': args.whitenv, 'whitenm': args.whitenm}
-    else:
-        net.pca = None
-        args.whiten = None
-
-    return extract_features(dataset, net, args.trfs, pooling=args.pooling, gemp=args.gemp, detailed=args.detailed,
-                            threads=args.threads, dbg=args.dbg, whiten=args.whiten, output=args.output)
+    net = load_model(args.checkpoint, iscuda)
+    whiten = test.select_whitening(net, args)
+    return extract_features(dataset, net, args.trfs, pooling=args.pooling, gemp=args.gemp,
+                            detailed=args.detailed, threads=args.threads, dbg=args.dbg, whiten=whiten,
+                            output=args.output)
 
 
 if __name__ == '__main__':

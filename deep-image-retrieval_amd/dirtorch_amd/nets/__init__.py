@@ -1,74 +1,66 @@
-"""Model factory - same surface as dirtorch/nets/__init__.py:18-95.
+"""Model factory with the surface of dirtorch/nets/__init__.py:18-95.
 
     net = create_model('resnet101_rmac', pretrained='', out_dim=2048, pooling='gem', gemp=3, ...)
     net.load_state_dict(checkpoint['state_dict']); desc = net(x)      # x: [B,3,H,W] fp32 on the GPU
+
+`model_names` holds the same 13 names as the reference; only the *_rmac trunks are
+on the descriptor hot path, the others resolve and raise NotImplementedError when instantiated.
 """
 import os
 from collections import OrderedDict
 
-import torch
+from . import rmac_resnet as _rmac
 
-internal_funcs = set(globals().keys())
+_FACTORIES = {name: getattr(_rmac, name) for name in (
+    'resnet18', 'resnet50', 'resnet101', 'resnet152',
+    'resnet18_rmac', 'resnet50_rmac', 'resnet101_rmac', 'resnet152_rmac',
+    'resnet18_fpn_rmac', 'resnet50_fpn_rmac', 'resnet101_fpn_rmac', 'resnet101_fpn0_rmac',
+    'resnet152_fpn_rmac')}
+globals().update(_FACTORIES)          # `nets.resnet101_rmac(...)` works as in the reference
+model_names = set(_FACTORIES)
 
-from .rmac_resnet import (resnet18_rmac, resnet50_rmac, resnet101_rmac, resnet152_rmac,  # noqa: E402
-                          resnet18, resnet50, resnet101, resnet152,
-                          resnet18_fpn_rmac, resnet50_fpn_rmac, resnet101_fpn_rmac,
-                          resnet101_fpn0_rmac, resnet152_fpn_rmac)
 
-# same rule as the reference (dirtorch/nets/__init__.py:18-21): every lowercase callable above
-model_names = {name for name in globals()
-               if name.islower() and not name.startswith("__")
-               and name not in internal_funcs
-               and callable(globals()[name])}
+def _strip_module_prefix(state_dict):
+    """DataParallel checkpoints prefix every key with 'module.' (common.py:153)."""
+    return OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in state_dict.items())
 
 
 def create_model(arch, pretrained='', delete_fc=False, *args, **kwargs):
-    """Create an (uninitialised-from-checkpoint) network; dirtorch/nets/__init__.py:24-64."""
-    if arch not in model_names:
-        raise NameError("unknown model architecture '%s'\nSelect one in %s" % (
-                        arch, ','.join(sorted(model_names))))
-    model = globals()[arch](*args, **kwargs)
+    """Instantiate architecture `arch` (NameError if unknown, like nets/__init__.py:37-39), attach
+    the `preprocess` dict the loaders read, and optionally initialise from a checkpoint file."""
+    factory = _FACTORIES.get(arch)
+    if factory is None:
+        raise NameError("unknown model architecture '%s'\nSelect one in %s"
+                        % (arch, ','.join(sorted(model_names))))
+    net = factory(*args, **kwargs)
+    net.preprocess = {'mean': net.rgb_means, 'std': net.rgb_stds, 'input_size': max(net.input_size)}
 
-    model.preprocess = dict(
-        mean=model.rgb_means,
-        std=model.rgb_stds,
-        input_size=max(model.input_size)
-    )
-
-    if os.path.isfile(pretrained or ''):
+    if pretrained:
+        if not os.path.isfile(pretrained):
+            # the reference would download ImageNet weights here (resnet.py:176-199): no network path
+            raise NotImplementedError("pretrained='%s': only a checkpoint file path is supported" % pretrained)
         from ..utils.common import torch_load_trusted
-        weights = torch_load_trusted(pretrained)['state_dict']
-        load_pretrained_weights(model, weights, delete_fc=delete_fc)
-    elif pretrained:
-        # the reference downloads ImageNet weights here (resnet.py:176-199); there is no network
-        # path in this engine
-        raise NotImplementedError("pretrained='%s': only a checkpoint file path is supported" % pretrained)
-
-    return model
+        load_pretrained_weights(net, torch_load_trusted(pretrained)['state_dict'], delete_fc=delete_fc)
+    return net
 
 
 def load_pretrained_weights(net, state_dict, delete_fc=False):
-    """Load what matches, keep the network's own value for what is missing or mis-shaped
-    (dirtorch/nets/__init__.py:67-95)."""
-    new_dict = OrderedDict()
-    for k, v in list(state_dict.items()):
-        if k.startswith('module.'):
-            k = k.replace('module.', '')
-        new_dict[k] = v
-
-    d = net.state_dict()
-    for k, v in list(d.items()):
-        if k not in new_dict:
-            if not k.endswith('num_batches_tracked'):
-                print("Loading weights for %s: Missing layer %s" % (type(net).__name__, k))
-            new_dict[k] = v
-        elif v.shape != new_dict[k].shape:
-            print("Loading weights for %s: Bad shape for layer %s, skipping" % (type(net).__name__, k))
-            new_dict[k] = v
-
-    net.load_state_dict(new_dict)
-
-    if delete_fc:
-        fc = net.fc_name
-        del new_dict[fc + '.weight']
-        del new_dict[fc + '.bias']
+    """Tolerant initialisation (nets/__init__.py:67-95): take every tensor of `state_dict` whose
+    name and shape match the network; keep the network's own value for the rest and say so."""
+    given = _strip_module_prefix(state_dict)
+    merged = OrderedDict()
+    for name, own in net.state_dict().items():
+        cand = given.get(name)
+        if cand is None:
+            if not name.endswith('num_batches_tracked'):
+                print("Loading weights for %s: Missing layer %s" % (type(net).__name__, name))
+            merged[name] = own
+        elif tuple(cand.shape) != tuple(own.shape):
+            print("Loading weights for %s: Bad shape for layer %s, skipping" % (type(net).__name__, name))
+            merged[name] = own
+        else:
+            merged[name] = cand
+    net.load_state_dict(merged)
+    if delete_fc:   # reference quirk kept: the caller's dict loses the FC entries
+        for suffix in ('.weight', '.bias'):
+            state_dict.pop(net.fc_name + suffix, None)

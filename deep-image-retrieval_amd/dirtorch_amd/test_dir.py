@@ -1,16 +1,17 @@
-"""Evaluation entry point - same functions and flags as dirtorch/test_dir.py.
+"""Retrieval evaluation on the MI355X engine - the functions and flags of dirtorch/test_dir.py.
 
     python -m dirtorch_amd.test_dir --dataset ROxford5K --checkpoint X.pt --whiten Landmarks_clean \
         --whitenp 0.25 --gpu 0
 
-    expand_descriptors        test_dir.py:24-44    (alpha query expansion / DB augmentation)
-    extract_image_features    test_dir.py:47-94    (the hot loop: loader -> net -> descriptors)
-    eval_model                test_dir.py:97-180   (extract -> pool -> whiten -> scores -> AP)
-    load_model                test_dir.py:183-191
+    expand_descriptors        test_dir.py:24-44    alpha query expansion / database augmentation
+    extract_image_features    test_dir.py:47-94    the hot loop: loader -> net -> [N, D] descriptors
+    eval_model                test_dir.py:97-180   extract -> pool -> whiten -> (QE) -> scores -> AP
+    load_model                test_dir.py:183-191  checkpoint -> engine-backed network
 
-All arithmetic runs on the engine (dirtorch_amd.nets / dirtorch_amd.utils.common); this file is
-orchestration only.  Under torch.distributed (one process per GPU) the database is sharded
-image-parallel and gathered once before ranking (dirtorch_amd.distributed).
+This file only orchestrates: descriptors, pooling, whitening, similarity and (for large databases)
+ranking are kernels of libdir_engine.so reached through dirtorch_amd.nets / .utils.common / .ranking.
+Under torch.distributed (one process per GPU) the database is sharded image-parallel and gathered
+once before ranking (dirtorch_amd.distributed).
 """
 import json
 import os
@@ -30,161 +31,143 @@ from .utils.pytorch_loader import get_loader
 
 
 def expand_descriptors(descs, db=None, alpha=0, k=0):
-    """alpha-weighted query expansion (db given) or database-side augmentation (db=None)."""
+    """Replace each descriptor by the L2-normalised mean of itself and its k nearest neighbours in
+    `db` (or among the other rows of `descs`), each neighbour weighted by similarity**alpha."""
     assert k >= 0 and alpha >= 0, 'k and alpha must be non-negative'
     if k == 0:
         return descs
     descs = tonumpy(descs)
-    n = descs.shape[0]
-    db_descs = tonumpy(db if db is not None else descs)
-
-    sim = matmul(descs, db_descs)            # fp32 MFMA similarity kernel
+    pool_ = descs if db is None else tonumpy(db)
+    sim = matmul(descs, pool_)                                   # fp32 MFMA similarity kernel
     if db is None:
-        sim[np.diag_indices(n)] = 0
-
-    idx = np.argpartition(sim, int(-k), axis=1)[:, int(-k):]
-    descs_aug = np.zeros_like(descs)
-    for i in range(n):
-        new_q = np.vstack([db_descs[j, :] * sim[i, j] ** alpha for j in idx[i]])
-        new_q = np.vstack([descs[i], new_q])
-        new_q = np.mean(new_q, axis=0)
-        descs_aug[i] = new_q / np.linalg.norm(new_q)
-    return descs_aug
+        np.fill_diagonal(sim, 0)                                 # a row is not its own neighbour
+    k = int(k)
+    nn = np.argpartition(sim, -k, axis=1)[:, -k:]                # [n, k] neighbour indices
+    w = np.take_along_axis(sim, nn, axis=1) ** alpha             # [n, k]
+    mixed = (descs + np.einsum('nk,nkd->nd', w, pool_[nn])) / (k + 1)
+    return (mixed / np.linalg.norm(mixed, axis=1, keepdims=True)).astype(descs.dtype, copy=False)
 
 
 def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=False, flip=None,
                            desc="Extract feats...", iscuda=True, threads=8, batch_size=8):
-    """Descriptors of every image of `dataset` -> Tensor [N, D] on the net's device.
-    Variable-size images force batch_size 1, as in the reference (test_dir.py:52-55)."""
-    if not same_size:
-        batch_size = 1
-
+    """One descriptor per image of `dataset`, as a [N, D] tensor on the network's device.
+    Images of different sizes cannot share a batch: unless `same_size`, batch_size is forced to 1
+    (the reference's real workload, test_dir.py:52-55)."""
+    bs = batch_size if same_size else 1
     loader = get_loader(dataset, trf_chain=transforms, preprocess=net.preprocess, iscuda=iscuda,
-                        output=['img'], batch_size=batch_size, threads=threads, shuffle=False)
-    if hasattr(net, 'eval'):
-        net.eval()
-
-    tocpu = (lambda x: x.cpu()) if ret_imgs == 'cpu' else (lambda x: x)
-    img_feats, trf_images = [], []
+                        output=['img'], batch_size=bs, threads=threads, shuffle=False)
+    net.eval()
+    feats, kept = [], []
+    nbatches = (len(dataset) + bs - 1) // bs
     with torch.no_grad():
-        for inputs in tqdm.tqdm(loader, desc, total=1 + (len(dataset) - 1) // batch_size):
-            imgs = inputs[0]
-            wdim = 2 if imgs.dtype == torch.uint8 else 3        # NHWC uint8 | NCHW float
-            for i in range(len(imgs)):
-                if flip and flip.pop(0):
-                    imgs[i] = imgs[i].flip(wdim - 1)
-            imgs = common.variables(inputs[:1], net.iscuda)[0]
+        for (imgs,) in tqdm.tqdm(loader, desc, total=nbatches):
+            if flip:
+                waxis = 1 if imgs.dtype == torch.uint8 else 2     # width axis of one HWC / CHW image
+                for i in range(len(imgs)):
+                    if flip and flip.pop(0):
+                        imgs[i] = imgs[i].flip(waxis)
+            imgs = common.variables([imgs], net.iscuda)[0]
             d = net(imgs)
+            feats.append(d.reshape(1, -1) if d.dim() == 1 else d)   # B == 1 comes back as [D]
             if ret_imgs:
-                trf_images.append(tocpu(imgs.detach()))
-            del imgs, inputs
-            if len(d.shape) == 1:
-                d = d.unsqueeze(0)
-            img_feats.append(d.detach())
+                kept.append(imgs.cpu() if ret_imgs == 'cpu' else imgs)
+    feats = torch.cat(feats, dim=0)
+    if not ret_imgs:
+        return feats
+    return (torch.cat(kept, dim=0) if same_size else kept), feats
 
-    img_feats = torch.cat(img_feats, dim=0)
-    if len(img_feats.shape) == 1:
-        img_feats = img_feats.unsqueeze(0)
-    if ret_imgs:
-        if same_size:
-            trf_images = torch.cat(trf_images, dim=0)
-        return trf_images, img_feats
-    return img_feats
+
+def _mean_ap(aps, detailed, res):
+    """Aggregate per-query APs the way test_dir.py:154-167 does: queries whose AP is -1 (no relevant
+    image in that mode) are left out of the mean."""
+    if isinstance(aps[0], dict):
+        for mode in aps[0]:
+            vals = [float(a[mode]) for a in aps]
+            if detailed:
+                res['APs-' + mode] = vals
+            res['mAP-' + mode] = float(np.mean([v for v in vals if v >= 0]))
+    else:
+        vals = [float(a) for a in aps]
+        if detailed:
+            res['APs'] = vals
+        res['mAP'] = float(np.mean([v for v in vals if v >= 0]))
 
 
 def eval_model(db, net, trfs, pooling='mean', gemp=3, detailed=False, whiten=None,
                aqe=None, adba=None, threads=8, batch_size=16, save_feats=None,
                load_feats=None, dbg=()):
-    """Evaluate a network on a retrieval dataset that carries its own AP protocol."""
+    """Evaluate `net` on a retrieval dataset that carries its own AP protocol; returns the dict of
+    mAP (and top-k, when the dataset has labels) the reference returns."""
     print("\n>> Evaluation...")
     query_db = db.get_query_db()
+    same_set = query_db is db
 
-    bdescs, qdescs = [], []
-    if not load_feats:
-        trfs_list = [trfs] if isinstance(trfs, str) else trfs
-        for trfs in trfs_list:
-            kw = dict(iscuda=net.iscuda, threads=threads, batch_size=batch_size,
-                      same_size='Pad' in trfs or 'Crop' in trfs)
-            # image-parallel shards + one all-gather when torch.distributed is initialised
-            bdescs.append(ddist.extract_sharded(extract_image_features, db, trfs, net, desc="DB", **kw))
-            qdescs.append(bdescs[-1] if db is query_db
-                          else extract_image_features(query_db, trfs, net, desc="query", **kw))
-        # pool over transforms (scales), then L2
-        bdescs = common.l2_normalize(pool(bdescs, pooling, gemp))
-        qdescs = common.l2_normalize(pool(qdescs, pooling, gemp))
-    else:
+    if load_feats:
         bdescs = np.load(os.path.join(load_feats, 'feats.bdescs.npy'))
-        qdescs = np.load(os.path.join(load_feats, 'feats.qdescs.npy')) if query_db is not db else bdescs
+        qdescs = bdescs if same_set else np.load(os.path.join(load_feats, 'feats.qdescs.npy'))
+    else:
+        per_scale_b, per_scale_q = [], []
+        for chain in ([trfs] if isinstance(trfs, str) else trfs):
+            kw = dict(iscuda=net.iscuda, threads=threads, batch_size=batch_size,
+                      same_size='Pad' in chain or 'Crop' in chain)
+            # image-parallel shards + one all-gather when torch.distributed is initialised
+            per_scale_b.append(ddist.extract_sharded(extract_image_features, db, chain, net, desc="DB", **kw))
+            per_scale_q.append(per_scale_b[-1] if same_set else
+                               extract_image_features(query_db, chain, net, desc="query", **kw))
+        bdescs = common.l2_normalize(pool(per_scale_b, pooling, gemp))    # multi-scale pooling, then L2
+        qdescs = common.l2_normalize(pool(per_scale_q, pooling, gemp))
 
     if save_feats:
         mkdir(save_feats)
         np.save(os.path.join(save_feats, 'feats.bdescs.npy'), tonumpy(bdescs))
-        if query_db is not db:
+        if not same_set:
             np.save(os.path.join(save_feats, 'feats.qdescs.npy'), tonumpy(qdescs))
 
     if whiten is not None:
         bdescs = common.whiten_features(tonumpy(bdescs), net.pca, **whiten)
         qdescs = common.whiten_features(tonumpy(qdescs), net.pca, **whiten)
-
-    # (the reference reads a module-global `args` here, test_dir.py:141,143; the parameters are meant)
+    # the reference reads a module-global `args` for these two (test_dir.py:141,143); the function
+    # parameters are what is meant
     if adba is not None:
         bdescs = expand_descriptors(bdescs, **adba)
     if aqe is not None:
         qdescs = expand_descriptors(qdescs, db=bdescs, **aqe)
 
-    # Large databases (>= 50k images, or DIRTORCH_AMD_DEVICE_RANK=1): keep the score matrix on the
-    # GPU and rank there (dirtorch_amd.ranking) instead of downloading it and argsort-ing every row.
+    # Large databases (>= 50k images, or DIRTORCH_AMD_DEVICE_RANK=1): the score matrix stays on the
+    # GPU and is ranked there instead of being downloaded and argsort-ed row by row.
     flag = os.environ.get('DIRTORCH_AMD_DEVICE_RANK', 'auto')
-    device_rank = hasattr(db, 'junk') and (flag == '1' or (flag == 'auto' and len(db) >= 50000))
-    if device_rank:
-        from . import ranking
-        scores_dev = ranking.similarity_device(qdescs, bdescs)
-        scores = []          # no per-row host scores: top-k below is skipped like for label-less sets
-    else:
-        scores = matmul(qdescs, bdescs)
-    del bdescs, qdescs
-
+    on_device = hasattr(db, 'junk') and (flag == '1' or (flag == 'auto' and len(db) >= 50000))
     res = {}
+    if on_device:
+        from . import ranking
+        aps = ranking.eval_aps_device(db, ranking.similarity_device(qdescs, bdescs))
+        _mean_ap(aps, detailed, res)
+        return res      # the revisitop datasets carry no labels: no top-k (dataset.py:97)
+
+    scores = matmul(qdescs, bdescs)
     try:
-        if device_rank:
-            aps = ranking.eval_aps_device(db, scores_dev)
-        else:
-            aps = [db.eval_query_AP(q, s) for q, s in enumerate(tqdm.tqdm(scores, desc='AP'))]
-        if not isinstance(aps[0], dict):
-            aps = [float(e) for e in aps]
-            if detailed:
-                res['APs'] = aps
-            res['mAP'] = float(np.mean([e for e in aps if e >= 0]))   # AP -1 = query without relevants
-        else:
-            for mode in aps[0].keys():
-                apst = [float(e[mode]) for e in aps]
-                if detailed:
-                    res['APs' + '-' + mode] = apst
-                res['mAP' + '-' + mode] = float(np.mean([e for e in apst if e >= 0]))
+        _mean_ap([db.eval_query_AP(q, s) for q, s in enumerate(tqdm.tqdm(scores, desc='AP'))], detailed, res)
     except NotImplementedError:
         print(" AP not implemented!")
-
     try:
-        if device_rank:
-            raise NotImplementedError()   # the revisitop datasets carry no labels (dataset.py:97)
         tops = [db.eval_query_top(q, s) for q, s in enumerate(tqdm.tqdm(scores, desc='top1'))]
         if detailed:
             res['tops'] = tops
         for k in tops[0]:
-            res['top%d' % k] = float(np.mean([top[k] for top in tops]))
+            res['top%d' % k] = float(np.mean([t[k] for t in tops]))
     except NotImplementedError:
         pass
     return res
 
 
 def load_model(path, iscuda):
-    checkpoint = common.load_checkpoint(path, iscuda)
-    net = nets.create_model(pretrained="", **checkpoint['model_options'])
-    net = common.switch_model_to_cuda(net, iscuda, checkpoint)
-    net.load_state_dict(checkpoint['state_dict'])
-    net.preprocess = checkpoint.get('preprocess', net.preprocess)
-    if 'pca' in checkpoint:
-        net.pca = checkpoint.get('pca')
+    """Checkpoint file -> network on the GPU, with `preprocess` and the PCA dict it may carry."""
+    ck = common.load_checkpoint(path, iscuda)
+    net = common.switch_model_to_cuda(nets.create_model(pretrained="", **ck['model_options']), iscuda, ck)
+    net.load_state_dict(ck['state_dict'])
+    net.preprocess = ck.get('preprocess', net.preprocess)
+    if 'pca' in ck:
+        net.pca = ck['pca']
     return net
 
 
@@ -194,69 +177,76 @@ def setup_devices(gpus):
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         ddist.init_from_env()
         return True
-    if gpus is None:
-        gpus = [0]
-    return common.torch_set_gpu(gpus)
+    return common.torch_set_gpu([0] if gpus is None else gpus)
 
 
-def build_parser(description='Evaluate a model'):
+# flags shared by test_dir and extract_features: (name, kwargs); same names/defaults as the reference
+_COMMON_FLAGS = [
+    (('--dataset', '-d'), dict(type=str, required=True, help='Command to load dataset')),
+    (('--checkpoint',), dict(type=str, required=True, help='path to weights')),
+    (('--trfs',), dict(type=str, required=False, default='', nargs='+', help='test transforms (can be several)')),
+    (('--pooling',), dict(type=str, default='gem', help='pooling scheme if several trf chains')),
+    (('--gemp',), dict(type=int, default=3, help='GeM pooling power')),
+    (('--out-json',), dict(type=str, default='', help='path to output json')),
+    (('--detailed',), dict(action='store_true', help='return detailed evaluation')),
+    (('--threads',), dict(type=int, default=8, help='number of thread workers')),
+    (('--dbg',), dict(default=(), nargs='*', help='debugging options')),
+    (('--whitenv',), dict(type=int, default=None, help='number of components, default is None (i.e. all components)')),
+    (('--whitenm',), dict(type=float, default=1.0, help='whitening multiplier, default is 1.0 (i.e. no multiplication)')),
+]
+
+
+def build_parser(description='Evaluate a model', extra=()):
     import argparse
     parser = argparse.ArgumentParser(description=description)
-    parser.add_argument('--dataset', '-d', type=str, required=True, help='Command to load dataset')
-    parser.add_argument('--checkpoint', type=str, required=True, help='path to weights')
-    parser.add_argument('--trfs', type=str, required=False, default='', nargs='+', help='test transforms (can be several)')
-    parser.add_argument('--pooling', type=str, default="gem", help='pooling scheme if several trf chains')
-    parser.add_argument('--gemp', type=int, default=3, help='GeM pooling power')
-    parser.add_argument('--out-json', type=str, default="", help='path to output json')
-    parser.add_argument('--detailed', action='store_true', help='return detailed evaluation')
-    parser.add_argument('--threads', type=int, default=8, help='number of thread workers')
-    parser.add_argument('--dbg', default=(), nargs='*', help='debugging options')
-    parser.add_argument('--whitenv', type=int, default=None, help='number of components, default is None (i.e. all components)')
-    parser.add_argument('--whitenm', type=float, default=1.0, help='whitening multiplier, default is 1.0 (i.e. no multiplication)')
+    for names, kw in list(_COMMON_FLAGS) + list(extra):
+        parser.add_argument(*names, **kw)
     return parser
 
 
+def select_whitening(net, args):
+    """--whiten NAME picks one PCA of the checkpoint's dict (test_dir.py:237-243)."""
+    if args.whiten:
+        net.pca = net.pca[args.whiten]
+        return {'whitenp': args.whitenp, 'whitenv': args.whitenv, 'whitenm': args.whitenm}
+    net.pca = None
+    return None
+
+
 def main(argv=None):
-    parser = build_parser()
-    parser.add_argument('--save-feats', type=str, default="", help='path to output features')
-    parser.add_argument('--load-feats', type=str, default="", help='path to load features from')
-    parser.add_argument('--gpu', type=int, default=0, nargs='+', help='GPU ids')
-    parser.add_argument('--whiten', type=str, default='Landmarks_clean', help='applies whitening')
-    parser.add_argument('--aqe', type=int, nargs='+', help='alpha-query expansion paramenters')
-    parser.add_argument('--adba', type=int, nargs='+', help='alpha-database augmentation paramenters')
-    parser.add_argument('--whitenp', type=float, default=0.25, help='whitening power, default is 0.5 (i.e., the sqrt)')
-    args = parser.parse_args(argv)
-    args.iscuda = setup_devices(args.gpu)
-    if args.aqe is not None:
-        args.aqe = {'k': args.aqe[0], 'alpha': args.aqe[1]}
-    if args.adba is not None:
-        args.adba = {'k': args.adba[0], 'alpha': args.adba[1]}
+    args = build_parser(extra=[
+        (('--save-feats',), dict(type=str, default='', help='path to output features')),
+        (('--load-feats',), dict(type=str, default='', help='path to load features from')),
+        (('--gpu',), dict(type=int, default=0, nargs='+', help='GPU ids')),
+        (('--whiten',), dict(type=str, default='Landmarks_clean', help='applies whitening')),
+        (('--aqe',), dict(type=int, nargs='+', help='alpha-query expansion paramenters')),
+        (('--adba',), dict(type=int, nargs='+', help='alpha-database augmentation paramenters')),
+        (('--whitenp',), dict(type=float, default=0.25, help='whitening power, default is 0.5 (i.e., the sqrt)')),
+    ]).parse_args(argv)
+    iscuda = setup_devices(args.gpu)
+    qe = {name: (None if val is None else {'k': val[0], 'alpha': val[1]})
+          for name, val in (('aqe', args.aqe), ('adba', args.adba))}
 
     dataset = datasets.create(args.dataset)
     print("Test dataset:", dataset)
-
-    net = load_model(args.checkpoint, args.iscuda)
-    if args.whiten:
-        net.pca = net.pca[args.whiten]
-        args.whiten = {'whitenp': args.whitenp, 'whitenv': args.whitenv, 'whitenm': args.whitenm}
-    else:
-        net.pca = None
-        args.whiten = None
+    net = load_model(args.checkpoint, iscuda)
+    whiten = select_whitening(net, args)
 
     res = eval_model(dataset, net, args.trfs, pooling=args.pooling, gemp=args.gemp, detailed=args.detailed,
-                     threads=args.threads, dbg=args.dbg, whiten=args.whiten, aqe=args.aqe, adba=args.adba,
+                     threads=args.threads, dbg=args.dbg, whiten=whiten, aqe=qe['aqe'], adba=qe['adba'],
                      save_feats=args.save_feats, load_feats=args.load_feats)
     if ddist.rank() == 0:
         # (--detailed adds per-query lists; the reference's '%g' print dies on them)
-        print(' * ' + '\n * '.join(['%s = %g' % p for p in res.items() if np.isscalar(p[1])]))
+        print(' * ' + '\n * '.join('%s = %g' % kv for kv in res.items() if np.isscalar(kv[1])))
         if args.out_json:
             try:
-                data = json.load(open(args.out_json))
+                merged = json.load(open(args.out_json))
             except IOError:
-                data = {}
-            data[args.dataset] = res
+                merged = {}
+            merged[args.dataset] = res
             mkdir(args.out_json, isfile=True)
-            open(args.out_json, 'w').write(json.dumps(data, indent=1))
+            with open(args.out_json, 'w') as f:
+                f.write(json.dumps(merged, indent=1))
             print("saved to " + args.out_json)
     return res
 

@@ -101,113 +101,96 @@ def whiten_features(X, pca, l2norm=True, whitenp=0.5, whitenv=None, whitenm=1.0,
     return res.cpu().numpy().astype(res_dtype, copy=False)
 
 
-# ---- runtime (common.py:58-218) ---------------------------------------------------------------
+# ---- runtime helpers (device selection, seeding, checkpoints; common.py:58-218) -----------------
 def torch_set_gpu(gpus, seed=None, randomize=True):
-    if type(gpus) is int:
-        gpus = [gpus]
-    assert gpus, 'error: empty gpu list, use --gpu N N ...'
-    cuda = all(gpu >= 0 for gpu in gpus)
-    if cuda:
-        if any(gpu >= 1000 for gpu in gpus):
-            visible_gpus = [int(gpu) for gpu in os.environ['CUDA_VISIBLE_DEVICES'].split(',')]
-            os.environ['CUDA_VISIBLE_DEVICES'] = ','.join([str(visible_gpus[gpu - 1000]) for gpu in gpus])
-        else:
-            os.environ['CUDA_VISIBLE_DEVICES'] = ','.join([str(gpu) for gpu in gpus])
-        assert cuda and torch.cuda.is_available(), "%s has GPUs %s unavailable" % (
-            os.environ.get('HOSTNAME', '?'), os.environ['CUDA_VISIBLE_DEVICES'])
-        print('Launching on GPUs ' + os.environ['CUDA_VISIBLE_DEVICES'])
-    else:
-        # the reference falls back to CPU here; this engine is MI355X-only by design
+    """Select the GPU(s) through CUDA_VISIBLE_DEVICES (honoured by PyTorch-ROCm) and seed the RNGs.
+    Ids >= 1000 index into the already-visible list, as in the reference.  Returns True; a negative
+    id (the reference's "run on CPU") is an error here: the engine is MI355X-only."""
+    ids = [gpus] if isinstance(gpus, int) else list(gpus)
+    assert ids, 'error: empty gpu list, use --gpu N N ...'
+    if any(g < 0 for g in ids):
         raise RuntimeError('dirtorch_amd has no CPU execution path: pass --gpu with a device id')
-    torch_set_seed(seed, cuda, randomize=randomize)
-    return cuda
+    if any(g >= 1000 for g in ids):
+        visible = [int(v) for v in os.environ['CUDA_VISIBLE_DEVICES'].split(',')]
+        ids = [visible[g - 1000] for g in ids]
+    os.environ['CUDA_VISIBLE_DEVICES'] = ','.join(str(g) for g in ids)
+    assert torch.cuda.is_available(), "%s has GPUs %s unavailable" % (
+        os.environ.get('HOSTNAME', '?'), os.environ['CUDA_VISIBLE_DEVICES'])
+    print('Launching on GPUs ' + os.environ['CUDA_VISIBLE_DEVICES'])
+    torch_set_seed(seed, True, randomize=randomize)
+    return True
 
 
 def torch_set_seed(seed, cuda, randomize=True):
-    if randomize and not seed:
-        import time
-        try:
-            seed = int(np.uint32(hash(time.time())))
-        except OverflowError:
-            seed = int.from_bytes(os.urandom(4), byteorder='little', signed=False)
-    if seed:
-        np.random.seed(seed)
-        torch.manual_seed(seed)
-        if cuda:
-            torch.cuda.manual_seed(seed)
+    """Seed numpy / torch (/ the GPU generator); with no seed and randomize=True draw one."""
+    if not seed and randomize:
+        seed = int.from_bytes(os.urandom(4), byteorder='little', signed=False)
+    if not seed:
+        return
+    np.random.seed(seed % (1 << 32))
+    torch.manual_seed(seed)
+    if cuda:
+        torch.cuda.manual_seed(seed)
 
 
 def torch_load_trusted(filename):
     """torch.load for the reference's checkpoint format.  Real checkpoints pickle an
     sklearn.decomposition.PCA under 'pca' (test_dir.py:189-190), which torch >= 2.6 refuses under
     weights_only=True - the checkpoint is a trusted local file, as in the reference (common.py:121)."""
-    return torch.load(filename, map_location=lambda storage, loc: storage, weights_only=False)
+    return torch.load(filename, map_location='cpu', weights_only=False)
 
 
 def save_checkpoint(state, is_best, filename):
-    import shutil
-    dirs = os.path.split(filename)[0]
-    if dirs and not os.path.isdir(dirs):
-        os.makedirs(dirs)
+    """torch.save with the reference's '.best' copy (common.py:102-114)."""
+    folder = os.path.dirname(filename)
+    if folder:
+        os.makedirs(folder, exist_ok=True)
     torch.save(state, filename)
     if is_best:
+        import shutil
         shutil.copyfile(filename, filename + '.best')
-        filename = filename + '.best'
-    print("saving to " + filename)
+    print("saving to " + (filename + '.best' if is_best else filename))
 
 
 def load_checkpoint(filename, iscuda=False):
+    """Read a checkpoint dict {'model_options', 'state_dict', ['preprocess'], ['pca'], ...} and drop
+    the DataParallel 'module.' prefix from its parameter names (common.py:117-147)."""
     if not filename:
         return None
     assert os.path.isfile(filename), "=> no checkpoint found at '%s'" % filename
-    checkpoint = torch_load_trusted(filename)
-    print("=> loading checkpoint '%s'" % filename, end='')
-    for key in ['epoch', 'iter', 'current_iter']:
-        if key in checkpoint:
-            print(" (%s %d)" % (key, checkpoint[key]), end='')
-    print()
-
-    new_dict = OrderedDict()
-    for k, v in list(checkpoint['state_dict'].items()):
-        if k.startswith('module.'):
-            k = k[7:]
-        new_dict[k] = v
-    checkpoint['state_dict'] = new_dict
-    return checkpoint
+    ck = torch_load_trusted(filename)
+    progress = ''.join(" (%s %d)" % (k, ck[k]) for k in ('epoch', 'iter', 'current_iter') if k in ck)
+    print("=> loading checkpoint '%s'%s" % (filename, progress))
+    ck['state_dict'] = OrderedDict((k[7:] if k.startswith('module.') else k, v)
+                                   for k, v in ck['state_dict'].items())
+    return ck
 
 
 def switch_model_to_cuda(model, iscuda=True, checkpoint=None):
-    """The reference wraps the model in nn.DataParallel here (common.py:150-175); this engine is
-    one process per GPU, so the model is simply placed on the current device.  Checkpoint keys are
-    left without the 'module.' prefix (load_state_dict accepts both)."""
-    if iscuda:
-        try:
-            model.cuda()
-            model.isasync = True
-        except RuntimeError as e:
-            print("RuntimeError:", e, "(machine %s, GPU %s)" % (
-                os.environ.get('HOSTNAME', '?'), os.environ.get('CUDA_VISIBLE_DEVICES', '?')),
-                file=sys.stderr)
-            sys.exit(1)
-    else:
+    """Place the model on the current GPU.  The reference wraps it in nn.DataParallel here
+    (common.py:150-175) and re-prefixes the checkpoint keys; this engine runs one process per GPU
+    (dirtorch_amd.distributed shards the work), so keys stay un-prefixed - load_state_dict takes both."""
+    if not iscuda:
         raise RuntimeError('dirtorch_amd has no CPU execution path (iscuda=False)')
-    model.iscuda = iscuda
+    try:
+        model.cuda()
+    except RuntimeError as e:
+        print("RuntimeError:", e, "(machine %s, GPU %s)" % (
+            os.environ.get('HOSTNAME', '?'), os.environ.get('CUDA_VISIBLE_DEVICES', '?')), file=sys.stderr)
+        sys.exit(1)
+    model.isasync = True
+    model.iscuda = True
     return model
 
 
 def model_size(model):
-    size = 0
-    for weights in model.state_dict().values():
-        size += np.prod(weights.shape)
-    return size
+    """Number of scalars in the state dict."""
+    return int(sum(int(np.prod(t.shape)) for t in model.state_dict().values()))
 
 
-def variables(inputs, iscuda, not_on_gpu=[]):
-    """Move a list of tensors to the GPU (common.py:205-218)."""
-    inputs_var = []
-    for i, x in enumerate(inputs):
-        if i not in not_on_gpu and not isinstance(x, (tuple, list)):
-            if iscuda:
-                x = x.cuda(non_blocking=True)
-        inputs_var.append(x)
-    return inputs_var
+def variables(inputs, iscuda, not_on_gpu=()):
+    """Move the tensors of `inputs` to the GPU (non-blocking), except indices in `not_on_gpu` and
+    nested lists (common.py:205-218; Variable wrapping is a no-op in today's torch)."""
+    return [x.cuda(non_blocking=True)
+            if iscuda and i not in not_on_gpu and not isinstance(x, (tuple, list)) else x
+            for i, x in enumerate(inputs)]

@@ -26,6 +26,9 @@ def short(name):
         return 'conv_igemm<%sx%s_w%sx%s%s%s>%s[%s]' % (bm, bn, wm, wn, '_s' + nst if nst != '2' else '',
                                                       '_k' + bk if bk != '64' else '',
                                                       '/stem' if c16 == 'true' else '', dt.lower())
+    m = re.search(r'conv1x1_persist_kernel<dir::(\w+)>', name)
+    if m:
+        return 'conv_igemm<256x256_persist1x1>[%s]' % m.group(1).lower()
     m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)>', name)
     if m:
         return 'conv_igemm<256x%s_patch3x3>[%s]' % (m.group(2), m.group(1).lower())
