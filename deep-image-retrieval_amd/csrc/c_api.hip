@@ -185,6 +185,7 @@ int dir_engine_tuning_import(dir_engine* e, const char* text) {
 int dir_engine_set_profiling(dir_engine* e, int enabled) {
     if (!e) return fail(DIR_ERR_INVALID, "set_profiling: null engine");
     e->profiling = enabled != 0;
+    e->prof_paused = false;
     e->prof_used = 0;
     // enabled > 1: pre-create that many event pairs so none is created inside a timed region
     while ((int)e->prof.size() < enabled && enabled > 1) {
@@ -193,6 +194,12 @@ int dir_engine_set_profiling(dir_engine* e, int enabled) {
         DIR_HIP_CHECK(hipEventCreate(&s.stop));
         e->prof.push_back(s);
     }
+    return DIR_OK;
+}
+
+int dir_engine_profile_pause(dir_engine* e, int paused) {
+    if (!e) return fail(DIR_ERR_INVALID, "profile_pause: null engine");
+    e->prof_paused = paused != 0;
     return DIR_OK;
 }
 

@@ -58,6 +58,7 @@ struct dir_engine {
     float* d_fc_b = nullptr;
     // profiling
     bool profiling = false;
+    bool prof_paused = false;
     std::vector<dir::ProfSlot> prof;
     size_t prof_used = 0;
     bool tuning = false;

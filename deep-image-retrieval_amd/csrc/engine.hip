@@ -267,7 +267,7 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
 // ---- profiling --------------------------------------------------------------------------------
 int dir_engine::prof_begin(const std::string& name, const std::string& kernel, double flops,
                            double bytes, hipStream_t stream) {
-    if (!profiling) return DIR_OK;
+    if (!profiling || prof_paused) return DIR_OK;
     if (prof_used == prof.size()) {
         ProfSlot s;
         DIR_HIP_CHECK(hipEventCreate(&s.start));
@@ -283,7 +283,7 @@ int dir_engine::prof_begin(const std::string& name, const std::string& kernel, d
     return DIR_OK;
 }
 int dir_engine::prof_end(hipStream_t stream) {
-    if (!profiling) return DIR_OK;
+    if (!profiling || prof_paused) return DIR_OK;
     DIR_HIP_CHECK(hipEventRecord(prof[prof_used].stop, stream));
     ++prof_used;
     return DIR_OK;

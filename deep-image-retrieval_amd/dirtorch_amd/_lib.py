@@ -55,6 +55,7 @@ SIGNATURES = {
     'dir_engine_tuning_export': (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_size_t)]),
     'dir_engine_tuning_import': (c_int, [c_void_p, c_char_p]),
     'dir_engine_set_profiling': (c_int, [c_void_p, c_int]),
+    'dir_engine_profile_pause': (c_int, [c_void_p, c_int]),
     'dir_engine_get_profile': (c_int, [c_void_p, POINTER(ProfRecord), c_int, POINTER(c_int)]),
     'dir_conv_variant_count': (c_int, []),
     'dir_conv_variant_name': (c_int, [c_int, c_char_p, c_int]),

@@ -288,6 +288,9 @@ class ResNet_RMAC(object):
             self._build_engine()
         call('dir_engine_set_profiling', self._engine, int(enabled))
 
+    def pause_profiling(self, paused):
+        call('dir_engine_profile_pause', self._engine, int(bool(paused)))
+
     def get_profile(self, cap=65536):
         recs = (_lib.ProfRecord * cap)()
         n = ctypes.c_int()

@@ -121,6 +121,9 @@ typedef struct dir_prof_record {
 /* enabled: 0 off, 1 on, n > 1 on with n event pairs pre-created (keeps event creation out of
  * a timed region). */
 int dir_engine_set_profiling(dir_engine* e, int enabled);
+/* Suspend / resume recording without dropping what was recorded (sample every n-th step of a
+ * timed loop so that the event records themselves stay out of most steps). */
+int dir_engine_profile_pause(dir_engine* e, int paused);
 /* Synchronises; copies up to `cap` records of the launches made since the last call. */
 int dir_engine_get_profile(dir_engine* e, dir_prof_record* out, int cap, int* n);
 
