@@ -102,7 +102,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run the RCCL path runs even at N = 1
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
 
