@@ -33,6 +33,13 @@ int dir_engine_create(const dir_model_desc* desc, int device, dir_engine** out) 
     if (desc->pooling < DIR_POOL_GEM || desc->pooling > DIR_POOL_AVG)
         return fail(DIR_ERR_INVALID, "create: bad pooling mode");  // ValueError(pooling), rmac_resnet.py:31
     if (!desc->without_fc && desc->out_dim <= 0) return fail(DIR_ERR_INVALID, "create: out_dim <= 0");
+    if (desc->head < DIR_HEAD_RMAC || desc->head > DIR_HEAD_CLASSIFIER)
+        return fail(DIR_ERR_INVALID, "create: bad head");
+    if ((desc->head == DIR_HEAD_FPN || desc->head == DIR_HEAD_FPN0) && desc->pooling != DIR_POOL_GEM)
+        // the reference only builds adpoolx5/adpoolc4 for 'gem' (rmac_resnet_fpn.py:39-45)
+        return fail(DIR_ERR_INVALID, "create: the FPN heads exist for GeM pooling only");
+    if (desc->head == DIR_HEAD_CLASSIFIER && desc->without_fc)
+        return fail(DIR_ERR_INVALID, "create: the classifier head needs its FC");
     int ndev = 0;
     DIR_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(DIR_ERR_INVALID, "create: no such device");
@@ -93,7 +100,7 @@ int dir_engine_finalize(dir_engine* e, int dtype) {
 
 int dir_engine_out_dim(const dir_engine* e, int* out_dim) {
     if (!e || !out_dim) return fail(DIR_ERR_INVALID, "out_dim: null argument");
-    *out_dim = e->desc.without_fc ? e->feat_dim : e->desc.out_dim;
+    *out_dim = e->desc.without_fc ? e->head_dim : e->desc.out_dim;
     return DIR_OK;
 }
 
@@ -310,7 +317,16 @@ int dir_global_pool(const void* x, float* out, int B, int H, int W, int C, int p
                     float eps, float center_bias, int dtype, void* stream) {
     DIR_TRY
     if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(DIR_ERR_INVALID, "global_pool: bad argument");
-    return global_pool(x, out, B, H, W, C, pooling, p, eps, center_bias, dtype, (hipStream_t)stream);
+    return global_pool(x, out, C, B, H, W, C, pooling, p, eps, center_bias, dtype, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
+                     int dtype, void* stream) {
+    DIR_TRY
+    if (!x || !low || !y || B <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || C <= 0)
+        return fail(DIR_ERR_INVALID, "upsample_add: bad argument");
+    return upsample_add(x, low, y, B, H, W, h, w, C, dtype, (hipStream_t)stream);
     DIR_CATCH
 }
 

@@ -38,7 +38,7 @@ struct ProfSlot {
 };
 
 struct Plan {  // byte offsets into the caller's workspace for one (B, H, W)
-    size_t s2d, stem, bufA, bufB, t1, t2, ds, pooled, fcout, total;
+    size_t s2d, stem, bufA, bufB, t1, t2, ds, x4, pooled, fcout, total;
     int H2, W2, OH1, OW1, PH, PW;
 };
 
@@ -53,7 +53,12 @@ struct dir_engine {
     std::vector<dir::ConvLayer> convs;
     std::vector<dir::BlockDef> blocks;
     int feat_dim = 0;  // trunk channels (512 * expansion)
-    float gem_p = 3.f;
+    int x4_dim = 0;    // layer3 channels (256 * expansion), FPN heads only
+    int head_dim = 0;  // width of the pooled vector that feeds the FC (feat_dim, or x4_dim + feat_dim)
+    int x4_block = -1; // index of the last layer3 block (its output is kept for the FPN heads)
+    int conv1x5 = -1, conv3c4 = -1;  // lateral convs of DIR_HEAD_FPN (no BatchNorm, no bias)
+    float gem_p = 3.f;   // adpool.p (RMAC) or adpoolx5.p (FPN)
+    float gem_p4 = 3.f;  // adpoolc4.p
     float* d_fc_w = nullptr;
     float* d_fc_b = nullptr;
     // profiling

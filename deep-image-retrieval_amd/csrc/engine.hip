@@ -103,6 +103,20 @@ int dir_engine::build_graph() {
         }
     }
     feat_dim = inplanes;
+    head_dim = feat_dim;
+    x4_dim = 0;
+    x4_block = conv1x5 = conv3c4 = -1;
+    if (desc.head == DIR_HEAD_FPN || desc.head == DIR_HEAD_FPN0) {
+        // rmac_resnet_fpn.py:24-32: dim1 = layer3 width, dim2 = layer4 width
+        x4_dim = 256 * expansion;
+        head_dim = x4_dim + feat_dim;
+        x4_block = desc.layers[0] + desc.layers[1] + desc.layers[2] - 1;
+        if (desc.head == DIR_HEAD_FPN) {
+            // 1x1 conv commutes with the nearest upsample, so it runs on the small x5 grid
+            conv1x5 = add_conv("conv1x5", "conv1x5.weight", "", feat_dim, x4_dim, 1, 1, 0, true);
+            conv3c4 = add_conv("conv3c4", "conv3c4.weight", "", x4_dim, x4_dim, 3, 1, 1, true);
+        }
+    }
     return DIR_OK;
 }
 
@@ -126,17 +140,18 @@ int dir_engine::finalize(int dt) {
         const HostTensor* mu = find(state, L.bnprefix + ".running_mean");
         const HostTensor* var = find(state, L.bnprefix + ".running_var");
         if (!w) return fail(DIR_ERR_MISSING, "missing tensor " + L.wkey);
-        if (!g || !bt || !mu || !var)
+        const bool has_bn = !L.bnprefix.empty();
+        if (has_bn && (!g || !bt || !mu || !var))
             return fail(DIR_ERR_MISSING, "missing BatchNorm tensors " + L.bnprefix + ".*");
         const int64_t want[4] = {L.Cout, L.Cin, L.R, L.S};
         if (w->shape.size() != 4 || !std::equal(want, want + 4, w->shape.begin()))
             return fail(DIR_ERR_INVALID, "bad shape for " + L.wkey);
-        if ((int)g->data.size() != L.Cout || (int)bt->data.size() != L.Cout ||
-            (int)mu->data.size() != L.Cout || (int)var->data.size() != L.Cout)
+        if (has_bn && ((int)g->data.size() != L.Cout || (int)bt->data.size() != L.Cout ||
+                       (int)mu->data.size() != L.Cout || (int)var->data.size() != L.Cout))
             return fail(DIR_ERR_INVALID, "bad BatchNorm shape for " + L.bnprefix);
 
-        std::vector<float> scale(L.Cout), bias(L.Cout);
-        for (int o = 0; o < L.Cout; ++o) {
+        std::vector<float> scale(L.Cout, 1.f), bias(L.Cout, 0.f);
+        for (int o = 0; has_bn && o < L.Cout; ++o) {
             // BatchNorm2d eval: y = (x - mean) / sqrt(var + eps) * gamma + beta, eps = 1e-5
             const float inv = 1.0f / sqrtf(var->data[o] + 1e-5f);
             scale[o] = g->data[o] * inv;
@@ -179,17 +194,22 @@ int dir_engine::finalize(int dt) {
         L.tuned.clear();
     }
 
-    if (desc.pooling == DIR_POOL_GEM) {
-        const HostTensor* p = find(state, "adpool.p");
-        if (!p || p->data.empty()) return fail(DIR_ERR_MISSING, "missing tensor adpool.p");
-        gem_p = p->data[0];
-        if (!(gem_p > 0.f)) return fail(DIR_ERR_INVALID, "adpool.p must be positive");
+    const bool fpn = desc.head == DIR_HEAD_FPN || desc.head == DIR_HEAD_FPN0;
+    if (desc.pooling == DIR_POOL_GEM && desc.head != DIR_HEAD_CLASSIFIER) {
+        const char* keys[2] = {fpn ? "adpoolx5.p" : "adpool.p", "adpoolc4.p"};
+        float* dst[2] = {&gem_p, &gem_p4};
+        for (int i = 0; i < (fpn ? 2 : 1); ++i) {
+            const HostTensor* p = find(state, keys[i]);
+            if (!p || p->data.empty()) return fail(DIR_ERR_MISSING, std::string("missing tensor ") + keys[i]);
+            *dst[i] = p->data[0];
+            if (!(*dst[i] > 0.f)) return fail(DIR_ERR_INVALID, std::string(keys[i]) + " must be positive");
+        }
     }
     if (!desc.without_fc) {
         const HostTensor* fw = find(state, "fc.weight");
         const HostTensor* fb = find(state, "fc.bias");
         if (!fw || !fb) return fail(DIR_ERR_MISSING, "missing tensor fc.weight / fc.bias");
-        if (fw->shape.size() != 2 || fw->shape[0] != desc.out_dim || fw->shape[1] != feat_dim ||
+        if (fw->shape.size() != 2 || fw->shape[0] != desc.out_dim || fw->shape[1] != head_dim ||
             (int)fb->data.size() != desc.out_dim)
             return fail(DIR_ERR_INVALID, "bad shape for fc.weight / fc.bias");
         DIR_HIP_CHECK(hipMalloc((void**)&d_fc_w, fw->data.size() * 4));
@@ -227,10 +247,11 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->OW1 = conv_out(W, 7, 2, 3);
     p->PH = conv_out(p->OH1, 3, 2, 1);
     p->PW = conv_out(p->OW1, 3, 2, 1);
-    size_t io = 0, t1 = 0, t2 = 0, ds = 0;
+    size_t io = 0, t1 = 0, t2 = 0, ds = 0, x4 = 0;
     int h = p->PH, w = p->PW;
     io = (size_t)B * h * w * 64 * 2;
-    for (const BlockDef& bd : blocks) {
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        const BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
         const ConvLayer& c1 = convs[bd.conv1];
         const ConvLayer& cl = convs[desc.bottleneck ? bd.conv3 : bd.conv2];
@@ -244,7 +265,12 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
         io = std::max(io, (size_t)B * oh * ow * cl.Cout * 2);
         h = oh;
         w = ow;
+        if ((int)bi == x4_block) {  // FPN heads keep x4; the lateral path reuses t1 / t2 / a ping-pong buffer
+            x4 = (size_t)B * h * w * x4_dim * 2;
+            t2 = std::max(t2, x4);
+        }
     }
+    if (conv1x5 >= 0) t1 = std::max(t1, (size_t)B * h * w * x4_dim * 2);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
@@ -258,8 +284,9 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->t1 = take(t1);
     p->t2 = take(t2 ? t2 : 256);
     p->ds = take(ds ? ds : 256);
-    p->pooled = take((size_t)B * feat_dim * 4);
-    p->fcout = take((size_t)B * std::max(desc.out_dim, feat_dim) * 4);
+    p->x4 = take(x4 ? x4 : 256);
+    p->pooled = take((size_t)B * head_dim * 4);
+    p->fcout = take((size_t)B * std::max(desc.out_dim, head_dim) * 4);
     p->total = off;
     return DIR_OK;
 }
@@ -381,7 +408,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     uint16_t* s2d = (uint16_t*)(base + p.s2d);
     uint16_t* stem = (uint16_t*)(base + p.stem);
     uint16_t* cur = (uint16_t*)(base + p.bufA);
-    uint16_t* nxt = (uint16_t*)(base + p.bufB);
+    uint16_t* nxt = nullptr;
     uint16_t* t1 = (uint16_t*)(base + p.t1);
     uint16_t* t2 = (uint16_t*)(base + p.t2);
     uint16_t* ds = (uint16_t*)(base + p.ds);
@@ -424,10 +451,15 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
     }
 
-    // 3. residual stages
-    int h = p.PH, w = p.PW;
-    for (BlockDef& bd : blocks) {
+    // 3. residual stages (two ping-pong buffers; the FPN heads park layer3's output in its own buffer)
+    uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
+    uint16_t* x4 = nullptr;
+    int h = p.PH, w = p.PW, h4 = 0, w4 = 0;
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
+        const bool keep = (int)bi == x4_block;
+        nxt = keep ? (uint16_t*)(base + p.x4) : (cur == pp[0] ? pp[1] : pp[0]);
         const uint16_t* resid = cur;
         if (bd.down >= 0) {
             rc = run_conv(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
@@ -447,9 +479,14 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             rc = run_conv(convs[bd.conv2], t1, resid, nxt, B, oh, ow, oh, ow, stream);
             if (rc != DIR_OK) return rc;
         }
-        std::swap(cur, nxt);
+        cur = nxt;
         h = oh;
         w = ow;
+        if (keep) {
+            x4 = cur;
+            h4 = h;
+            w4 = w;
+        }
     }
     if (feat_out) {
         DIR_HIP_CHECK(hipMemcpyAsync(feat_out, cur, (size_t)B * h * w * feat_dim * 2,
@@ -460,32 +497,61 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     }
     if (!desc_out) return DIR_OK;
 
-    // 4. head: global pool -> (L2) -> FC -> L2   (rmac_resnet.py:58-68)
-    rc = prof_begin("adpool", "global_pool", 0, (double)B * h * w * feat_dim * 2 + (double)B * feat_dim * 4,
-                    stream);
+    // 4. head (rmac_resnet.py:58-68; rmac_resnet_fpn.py:53-86; resnet.py:169-173)
+    const bool fpn = x4 != nullptr;
+    const bool classifier = desc.head == DIR_HEAD_CLASSIFIER;
+    if (fpn) {
+        const uint16_t* c4 = x4;
+        if (conv1x5 >= 0) {
+            uint16_t* sum = cur == pp[0] ? pp[1] : pp[0];
+            rc = run_conv(convs[conv1x5], cur, nullptr, t1, B, h, w, h, w, stream);
+            if (rc != DIR_OK) return rc;
+            rc = prof_begin("x4+up(c5)", "upsample_add", 0,
+                            2.0 * ((double)B * h4 * w4 * x4_dim * 2 + (double)B * h * w * x4_dim), stream);
+            if (rc != DIR_OK) return rc;
+            rc = upsample_add(x4, t1, sum, B, h4, w4, h, w, x4_dim, dtype, stream);
+            if (rc != DIR_OK) return rc;
+            if ((rc = prof_end(stream)) != DIR_OK) return rc;
+            rc = run_conv(convs[conv3c4], sum, nullptr, t2, B, h4, w4, h4, w4, stream);
+            if (rc != DIR_OK) return rc;
+            c4 = t2;
+        }
+        rc = prof_begin("adpoolc4", "global_pool", 0, (double)B * h4 * w4 * x4_dim * 2, stream);
+        if (rc != DIR_OK) return rc;
+        rc = global_pool(c4, pooled, head_dim, B, h4, w4, x4_dim, DIR_POOL_GEM, gem_p4, 1e-6f, 0.f,
+                         dtype, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    }
+    rc = prof_begin(fpn ? "adpoolx5" : "adpool", "global_pool", 0,
+                    (double)B * h * w * feat_dim * 2 + (double)B * feat_dim * 4, stream);
     if (rc != DIR_OK) return rc;
-    rc = global_pool(cur, pooled, B, h, w, feat_dim, desc.pooling, gem_p, 1e-6f, desc.center_bias,
-                     dtype, stream);
+    // the FPN forward never applies center_bias (rmac_resnet_fpn.py:50-86), the classifier averages
+    rc = global_pool(cur, pooled + (fpn ? x4_dim : 0), head_dim, B, h, w, feat_dim,
+                     classifier ? DIR_POOL_AVG : desc.pooling, gem_p, 1e-6f,
+                     (fpn || classifier) ? 0.f : desc.center_bias, dtype, stream);
     if (rc != DIR_OK) return rc;
     if ((rc = prof_end(stream)) != DIR_OK) return rc;
-    if (desc.norm_features) {
-        rc = l2norm_rows(pooled, B, feat_dim, 1e-12f, stream);
+    if (desc.norm_features && !classifier) {
+        rc = l2norm_rows(pooled, B, head_dim, 1e-12f, stream);
         if (rc != DIR_OK) return rc;
     }
-    const int D = desc.without_fc ? feat_dim : desc.out_dim;
+    const int D = desc.without_fc ? head_dim : desc.out_dim;
     if (!desc.without_fc) {
-        rc = prof_begin("fc", "gemm_nt_f32", 2.0 * B * feat_dim * (double)D,
-                        4.0 * ((double)D * feat_dim + (double)B * (feat_dim + D)), stream);
+        rc = prof_begin("fc", "gemm_nt_f32", 2.0 * B * head_dim * (double)D,
+                        4.0 * ((double)D * head_dim + (double)B * (head_dim + D)), stream);
         if (rc != DIR_OK) return rc;
-        rc = gemm_nt_f32(d_fc_w, feat_dim, pooled, feat_dim, fcout, D, D, B, feat_dim, nullptr,
+        rc = gemm_nt_f32(d_fc_w, head_dim, pooled, head_dim, fcout, D, D, B, head_dim, nullptr,
                          d_fc_b, nullptr, stream);
         if (rc != DIR_OK) return rc;
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
     } else {
         fcout = pooled;
     }
-    rc = l2norm_rows(fcout, B, D, 1e-12f, stream);
-    if (rc != DIR_OK) return rc;
+    if (!classifier) {
+        rc = l2norm_rows(fcout, B, D, 1e-12f, stream);
+        if (rc != DIR_OK) return rc;
+    }
     DIR_HIP_CHECK(hipMemcpyAsync(desc_out, fcout, (size_t)B * D * 4, hipMemcpyDeviceToDevice, stream));
     return DIR_OK;
 }

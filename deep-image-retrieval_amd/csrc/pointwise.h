@@ -7,8 +7,11 @@ namespace dir {
 int prep_input(const void* img, int fmt, const float* mean3, const float* std3, void* out, int B,
                int H, int W, int dtype, hipStream_t stream);
 int maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, hipStream_t stream);
-int global_pool(const void* x, float* out, int B, int H, int W, int C, int pooling, float p,
+// out row b starts at out + b * ldo (the FPN heads pool two maps into one concatenated row)
+int global_pool(const void* x, float* out, int ldo, int B, int H, int W, int C, int pooling, float p,
                 float eps, float center_bias, int dtype, hipStream_t stream);
+int upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
+                 int dtype, hipStream_t stream);
 int l2norm_rows(float* x, int rows, int cols, float eps, hipStream_t stream);
 int multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                     hipStream_t stream);

@@ -3,6 +3,7 @@
 //   maxpool_3x3s2     dirtorch/nets/backbones/resnet.py:119
 //   global_pool       GeM / max / avg over H*W (dirtorch/nets/layers/pooling.py:38-40,
 //                     dirtorch/nets/rmac_resnet.py:24-31,52-59)
+//   upsample_add      x4 + nearest-upsampled lateral map (dirtorch/nets/rmac_resnet_fpn.py:55-60)
 //   l2norm_rows       F.normalize(p=2) (dirtorch/nets/rmac_resnet.py:7-9)
 //   multiscale_pool   dirtorch/utils/common.py:41-55
 // All of them move 16 bytes per lane and keep every reduction in fp32.
@@ -172,8 +173,8 @@ __device__ inline float center_mask(int h, int w, int H, int W, float cb) {
 
 template <class DT, int POOL>
 __global__ void __launch_bounds__(256) global_pool_kernel(const uint16_t* __restrict__ x,
-                                                         float* __restrict__ out, int H, int W,
-                                                         int C, float p, float eps, float cb) {
+                                                         float* __restrict__ out, int ldo, int H,
+                                                         int W, int C, float p, float eps, float cb) {
     __shared__ float part[32][64 + 1];
     const int b = blockIdx.y;
     const int c0 = blockIdx.x * 64;
@@ -231,11 +232,11 @@ __global__ void __launch_bounds__(256) global_pool_kernel(const uint16_t* __rest
             r = powf(r / (float)HW, 1.f / p);
         else if (POOL == DIR_POOL_AVG)
             r = r / (float)HW;
-        out[(size_t)b * C + c0 + threadIdx.x] = r;
+        out[(size_t)b * ldo + c0 + threadIdx.x] = r;
     }
 }
 
-int global_pool(const void* x, float* out, int B, int H, int W, int C, int pooling, float p,
+int global_pool(const void* x, float* out, int ldo, int B, int H, int W, int C, int pooling, float p,
                 float eps, float center_bias, int dtype, hipStream_t stream) {
     if (C % 64 != 0) return fail(DIR_ERR_INVALID, "global_pool: C must be a multiple of 64");
     if (pooling == DIR_POOL_GEM && !(p > 0.f)) return fail(DIR_ERR_INVALID, "global_pool: p <= 0");
@@ -243,7 +244,7 @@ int global_pool(const void* x, float* out, int B, int H, int W, int C, int pooli
     const dim3 grid(C / 64, B);
 #define DIR_GP(DT, POOL)                                                                      \
     hipLaunchKernelGGL((global_pool_kernel<DT, POOL>), grid, dim3(256), 0, stream,            \
-                       (const uint16_t*)x, out, H, W, C, p, eps, center_bias)
+                       (const uint16_t*)x, out, ldo, H, W, C, p, eps, center_bias)
     if (pooling == DIR_POOL_GEM) {
         if (dtype == DIR_BF16) DIR_GP(BF16, DIR_POOL_GEM); else DIR_GP(FP16, DIR_POOL_GEM);
     } else if (pooling == DIR_POOL_MAX) {
@@ -254,6 +255,53 @@ int global_pool(const void* x, float* out, int B, int H, int W, int C, int pooli
         return fail(DIR_ERR_INVALID, "global_pool: bad pooling mode");
     }
 #undef DIR_GP
+    DIR_HIP_CHECK(hipGetLastError());
+    return DIR_OK;
+}
+
+// ---- upsample_add ------------------------------------------------------------------------------
+// y[b][Y][X][:] = x[b][Y][X][:] + low[b][sy(Y)][sx(X)][:], the x4 + F.interpolate(c5, size=x4.shape[-2:],
+// mode='nearest') of dirtorch/nets/rmac_resnet_fpn.py:55-60.  Source index as PyTorch computes it:
+// min(floor(dst * (float)in / out), in - 1).
+template <class DT>
+__global__ void upsample_add_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ low,
+                                    uint16_t* __restrict__ y, long total, int H, int W, int h, int w,
+                                    int C8, float sy, float sx) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const long pix = idx / C8;
+    const int X = (int)(pix % W);
+    const int Y = (int)((pix / W) % H);
+    const long b = pix / ((long)W * H);
+    const int ys = min((int)floorf(Y * sy), h - 1);
+    const int xs = min((int)floorf(X * sx), w - 1);
+    const u32x4_t a = gload16(x + idx * 8);
+    const u32x4_t l = gload16(low + (((b * h + ys) * w + xs) * C8 + c8) * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a0, a1, l0, l1;
+        DT::unpack(a[e], a0, a1);
+        DT::unpack(l[e], l0, l1);
+        o[e] = DT::pack(a0 + l0, a1 + l1);
+    }
+    gstore16(y + idx * 8, o);
+}
+
+int upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
+                 int dtype, hipStream_t stream) {
+    if (C % 8 != 0) return fail(DIR_ERR_INVALID, "upsample_add: C must be a multiple of 8");
+    if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "upsample_add: bad dtype");
+    const long total = (long)B * H * W * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    if (dtype == DIR_BF16)
+        hipLaunchKernelGGL(upsample_add_kernel<BF16>, grid, dim3(256), 0, stream, (const uint16_t*)x,
+                           (const uint16_t*)low, (uint16_t*)y, total, H, W, h, w, C / 8, sy, sx);
+    else
+        hipLaunchKernelGGL(upsample_add_kernel<FP16>, grid, dim3(256), 0, stream, (const uint16_t*)x,
+                           (const uint16_t*)low, (uint16_t*)y, total, H, W, h, w, C / 8, sy, sx);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;
 }

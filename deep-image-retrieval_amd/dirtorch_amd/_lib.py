@@ -15,6 +15,7 @@ DIR_BF16, DIR_FP16 = 0, 1
 DIR_IMG_F32_NCHW, DIR_IMG_U8_NHWC = 0, 1
 DIR_POOL_GEM, DIR_POOL_MAX, DIR_POOL_AVG = 0, 1, 2
 POOLING = {'gem': DIR_POOL_GEM, 'max': DIR_POOL_MAX, 'avg': DIR_POOL_AVG}
+DIR_HEAD_RMAC, DIR_HEAD_FPN, DIR_HEAD_FPN0, DIR_HEAD_CLASSIFIER = 0, 1, 2, 3
 
 
 class DirError(RuntimeError):
@@ -28,7 +29,8 @@ class DirError(RuntimeError):
 class ModelDesc(Structure):
     _fields_ = [('bottleneck', c_int), ('layers', c_int * 4), ('out_dim', c_int),
                 ('norm_features', c_int), ('pooling', c_int), ('without_fc', c_int),
-                ('center_bias', c_float), ('mean', c_float * 3), ('std', c_float * 3)]
+                ('center_bias', c_float), ('mean', c_float * 3), ('std', c_float * 3),
+                ('head', c_int)]
 
 
 class ProfRecord(Structure):
@@ -70,6 +72,8 @@ SIGNATURES = {
     'dir_maxpool_3x3s2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dir_global_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 c_float, c_float, c_int, c_void_p]),
+    'dir_upsample_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
     'dir_l2norm_rows': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     'dir_gemm_nt_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

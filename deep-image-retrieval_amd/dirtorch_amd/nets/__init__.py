@@ -3,8 +3,9 @@
     net = create_model('resnet101_rmac', pretrained='', out_dim=2048, pooling='gem', gemp=3, ...)
     net.load_state_dict(checkpoint['state_dict']); desc = net(x)      # x: [B,3,H,W] fp32 on the GPU
 
-`model_names` holds the same 13 names as the reference; only the *_rmac trunks are
-on the descriptor hot path, the others resolve and raise NotImplementedError when instantiated.
+`model_names` holds the same 13 names as the reference: the *_rmac networks of the
+descriptor hot path, the *_fpn_rmac two-level variants and the plain classification trunks, all
+engine-backed.
 """
 import os
 from collections import OrderedDict

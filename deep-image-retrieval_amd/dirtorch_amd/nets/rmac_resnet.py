@@ -36,6 +36,9 @@ def _default_dtype():
 class ResNet_RMAC(object):
     """ResNet trunk + global pooling + FC + L2 (without ROI pooling), engine-backed."""
 
+    HEAD = _lib.DIR_HEAD_RMAC      # dir_head of include/dir_engine.h
+    SQUEEZE = True                 # x.squeeze_() before the FC (rmac_resnet.py:64): [D] at B == 1
+
     def __init__(self, model_name, out_dim=2048, norm_features=False, pooling='gem', gemp=3,
                  center_bias=0, dropout_p=None, without_fc=False, **kwargs):
         if kwargs:
@@ -104,12 +107,23 @@ class ResNet_RMAC(object):
             sd[bn + '.running_mean'] = torch.zeros(cout)
             sd[bn + '.running_var'] = torch.ones(cout)
             sd[bn + '.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+        self._init_head_state(sd)
+        return sd
+
+    def _head_in_dim(self):
+        """Width of the pooled vector that feeds the FC."""
+        return self.trunk_dim
+
+    def _init_head_state(self, sd):
         if self.pooling.startswith('gem'):
             sd['adpool.p'] = torch.ones(1) * self._gemp
-        bound = 1. / math.sqrt(self.trunk_dim)
-        sd['fc.weight'] = (torch.rand(self.out_dim, self.trunk_dim) * 2 - 1) * bound
+        self._init_fc_state(sd)
+
+    def _init_fc_state(self, sd):
+        fan_in = self._head_in_dim()
+        bound = 1. / math.sqrt(fan_in)
+        sd['fc.weight'] = (torch.rand(self.out_dim, fan_in) * 2 - 1) * bound
         sd['fc.bias'] = (torch.rand(self.out_dim) * 2 - 1) * bound
-        return sd
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._state.items())
@@ -169,6 +183,7 @@ class ResNet_RMAC(object):
             d.pooling = POOLING['gem' if self.pooling.startswith('gem') else self.pooling]
             d.without_fc = int(bool(self.without_fc))
             d.center_bias = float(self.center_bias)
+            d.head = self.HEAD
             mean, std = self._norm_constants()
             for i in range(3):
                 d.mean[i] = mean[i]
@@ -256,11 +271,11 @@ class ResNet_RMAC(object):
 
     def forward(self, x):
         x, B, H, W, fmt, ws = self._prepare(x)
-        D = self.trunk_dim if self.without_fc else self.out_dim
+        D = self._head_in_dim() if self.without_fc else self.out_dim
         out = torch.empty(B, D, dtype=torch.float32, device=x.device)
         call('dir_forward', self._engine, ptr(x), B, H, W, fmt, ptr(out), ptr(ws), ws.numel(),
              stream_ptr())
-        if B == 1:
+        if B == 1 and self.SQUEEZE:
             out = out.view(D)   # x.squeeze_() of the reference (rmac_resnet.py:64)
         return out
 
@@ -325,22 +340,96 @@ resnet101_rmac = _rmac('resnet101')
 resnet152_rmac = _rmac('resnet152')
 
 
-def _not_on_path(name, why):
-    def factory(*args, **kwargs):
-        raise NotImplementedError('%s is registered for name compatibility with dirtorch.nets but '
-                                  'is outside the descriptor hot path (%s)' % (name, why))
+class ResNet_RMAC_FPN(ResNet_RMAC):
+    """Two-level variant (dirtorch/nets/rmac_resnet_fpn.py:11-90): layer3's map, merged with the
+    upsampled layer4 map through conv1x5 / conv3c4 when mode == 1, is GeM-pooled next to layer4's;
+    the concatenation feeds the FC.  center_bias is accepted and, as in the reference forward, unused."""
+
+    def __init__(self, model_name, out_dim=None, norm_features=False, pooling='gem', gemp=3,
+                 center_bias=0, mode=1, dropout_p=None, without_fc=False, **kwargs):
+        bottleneck, _ = _ARCH[model_name]
+        expansion = 4 if bottleneck else 1
+        self.mode = mode
+        self.dim1, self.dim2 = 256 * expansion, 512 * expansion
+        if out_dim is None:
+            out_dim = self.dim1 + self.dim2          # rmac_resnet_fpn.py:26
+        # the reference constructor accepts any pooling string and only fails inside forward
+        self._fpn_pooling = pooling
+        ResNet_RMAC.__init__(self, model_name, out_dim=out_dim, norm_features=norm_features,
+                             pooling='gem', gemp=gemp, center_bias=center_bias,
+                             dropout_p=dropout_p, without_fc=without_fc, **kwargs)
+        self.pooling = pooling
+
+    @property
+    def HEAD(self):
+        return _lib.DIR_HEAD_FPN if self.mode == 1 else _lib.DIR_HEAD_FPN0
+
+    def _head_in_dim(self):
+        return self.dim1 + self.dim2
+
+    def _init_head_state(self, sd):
+        if self.mode == 1:      # rmac_resnet_fpn.py:28-31,33-36
+            sd['conv1x5.weight'] = torch.randn(self.dim1, self.dim2, 1, 1) * math.sqrt(2. / self.dim1)
+            sd['conv3c4.weight'] = torch.randn(self.dim1, self.dim1, 3, 3) * math.sqrt(2. / (9 * self.dim1))
+        if self._fpn_pooling == 'gem':
+            sd['adpoolx5.p'] = torch.ones(1) * self._gemp
+            sd['adpoolc4.p'] = torch.ones(1) * self._gemp
+        self._init_fc_state(sd)
+
+    def forward(self, x):
+        if self._fpn_pooling != 'gem':
+            # rmac_resnet_fpn.py:38-45 builds adpoolx5/adpoolc4 for 'gem' only; forward then dies here
+            raise AttributeError("'ResNet_RMAC_FPN' object has no attribute 'adpoolx5'")
+        return ResNet_RMAC.forward(self, x)
+
+    __call__ = forward
+
+    def _build_engine(self):
+        self.pooling, keep = 'gem', self.pooling
+        try:
+            ResNet_RMAC._build_engine(self)
+        finally:
+            self.pooling = keep
+
+
+class ResNet(ResNet_RMAC):
+    """The plain classification trunk (dirtorch/nets/backbones/resnet.py:102-174): conv stages ->
+    average pool -> FC, logits [B, fc_out] with no normalisation and no squeeze."""
+
+    HEAD = _lib.DIR_HEAD_CLASSIFIER
+    SQUEEZE = False
+
+    def __init__(self, model_name, fc_out=2048):
+        if fc_out <= 0:
+            raise NotImplementedError('fc_out = 0 returns the raw feature map in the reference; '
+                                      'use forward_features() of a *_rmac network for that')
+        self.fc_out = fc_out
+        ResNet_RMAC.__init__(self, model_name, out_dim=fc_out, pooling='avg')
+
+    def _init_head_state(self, sd):
+        self._init_fc_state(sd)
+
+
+def _fpn(name, **fixed):
+    def factory(backbone=ResNet_RMAC_FPN, **kwargs):
+        kwargs.pop('scales', None)   # rmac_resnet_fpn.py:121
+        kwargs.update(fixed)
+        return backbone(name, **kwargs)
+    factory.__name__ = name + ('_fpn0_rmac' if fixed else '_fpn_rmac')
+    return factory
+
+
+def _classifier(name):
+    def factory(out_dim=2048):      # resnet.py:205-227
+        return ResNet(name, out_dim)
     factory.__name__ = name
     return factory
 
 
-# classification trunks (resnet.py:205-227) and FPN heads (rmac_resnet_fpn.py): names resolve, as in
-# the reference's model_names, but none of the five released retrieval models uses them.
-resnet18 = _not_on_path('resnet18', 'ImageNet classifier')
-resnet50 = _not_on_path('resnet50', 'ImageNet classifier')
-resnet101 = _not_on_path('resnet101', 'ImageNet classifier')
-resnet152 = _not_on_path('resnet152', 'ImageNet classifier')
-resnet18_fpn_rmac = _not_on_path('resnet18_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
-resnet50_fpn_rmac = _not_on_path('resnet50_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
-resnet101_fpn_rmac = _not_on_path('resnet101_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
-resnet101_fpn0_rmac = _not_on_path('resnet101_fpn0_rmac', 'FPN variant, SURVEY.md §8f N4')
-resnet152_fpn_rmac = _not_on_path('resnet152_fpn_rmac', 'FPN variant, SURVEY.md §8f N4')
+resnet18, resnet50, resnet101, resnet152 = (_classifier(n) for n in
+                                            ('resnet18', 'resnet50', 'resnet101', 'resnet152'))
+resnet18_fpn_rmac = _fpn('resnet18')
+resnet50_fpn_rmac = _fpn('resnet50')
+resnet101_fpn_rmac = _fpn('resnet101')
+resnet101_fpn0_rmac = _fpn('resnet101', mode=0)
+resnet152_fpn_rmac = _fpn('resnet152')

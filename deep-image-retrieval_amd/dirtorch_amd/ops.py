@@ -120,6 +120,19 @@ def global_pool(x, pooling='gem', p=3.0, eps=1e-6, center_bias=0.0):
     return out
 
 
+def upsample_add(x, low):
+    """x + nearest-upsampled low: NHWC 16-bit [B,H,W,C] and [B,h,w,C] (rmac_resnet_fpn.py:55-60)."""
+    _need_cuda(x, low)
+    if x.dtype != low.dtype or x.shape[0] != low.shape[0] or x.shape[3] != low.shape[3]:
+        raise ValueError('upsample_add: x and low must share dtype, batch and channels')
+    x, low = x.contiguous(), low.contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    call('dir_upsample_add', ptr(x), ptr(low), ptr(y), B, H, W, low.shape[1], low.shape[2], C,
+         _dtype_code(x), stream_ptr())
+    return y
+
+
 def l2norm_rows_(x, eps=1e-12):
     """In place: x[i] /= max(||x[i]||, eps)."""
     _need_cuda(x)

@@ -55,6 +55,14 @@ typedef enum dir_pooling {    /* dirtorch/nets/rmac_resnet.py:24-31             
     DIR_POOL_AVG = 2
 } dir_pooling;
 
+typedef enum dir_head {       /* what follows the trunk                                     */
+    DIR_HEAD_RMAC = 0,        /* ResNet_RMAC: pool -> (L2) -> FC -> L2 (rmac_resnet.py:39-69)       */
+    DIR_HEAD_FPN = 1,         /* ResNet_RMAC_FPN mode 1: c4 = relu(conv3c4(x4 + up(relu(conv1x5(x5)))));
+                                 GeM(c4) ++ GeM(x5) -> (L2) -> FC -> L2 (rmac_resnet_fpn.py:50-86)  */
+    DIR_HEAD_FPN0 = 2,        /* mode 0 (resnet101_fpn0_rmac): GeM(x4) ++ GeM(x5), no lateral convs */
+    DIR_HEAD_CLASSIFIER = 3   /* plain ResNet: avgpool -> FC, no L2 (backbones/resnet.py:169-174)   */
+} dir_head;
+
 /* Mirrors the keyword arguments of ResNet_RMAC.__init__ (dirtorch/nets/rmac_resnet.py:15-17)
  * and the layer counts of the resnet{18,50,101,152}_rmac factories (:74-88). */
 typedef struct dir_model_desc {
@@ -67,6 +75,8 @@ typedef struct dir_model_desc {
     float center_bias;        /* >0: bilinear 4x4 centre mask before pooling (:52-56)       */
     float mean[3];            /* used by DIR_IMG_U8_NHWC only                               */
     float std[3];
+    int   head;               /* dir_head; FPN heads need pooling == DIR_POOL_GEM and read the
+                                 keys conv1x5.weight, conv3c4.weight, adpoolx5.p, adpoolc4.p   */
 } dir_model_desc;
 
 typedef struct dir_engine dir_engine;
@@ -157,6 +167,11 @@ int dir_maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dt
  * center_bias > 0 applies the bilinear mask of rmac_resnet.py:52-56 first. */
 int dir_global_pool(const void* x, float* out, int B, int H, int W, int C, int pooling, float p,
                     float eps, float center_bias, int dtype, void* stream);
+/* FPN lateral merge: y = x + nearest_upsample(low) with x,y NHWC [B,H,W,C], low [B,h,w,C], 16-bit;
+ * source index min(floor(dst * in/out), in-1) as F.interpolate(mode='nearest', size=...) computes it
+ * (dirtorch/nets/rmac_resnet_fpn.py:55-60).  C % 8 == 0. */
+int dir_upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
+                     int dtype, void* stream);
 /* L2-normalise each row in place: x / max(||x||, eps) (F.normalize, rmac_resnet.py:7-9). */
 int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream);
 /* K9/K11/K12: out[j][i] = alpha_i * (sum_k P[i][k] * (Q[j][k] - qsub[k])) + bias[i]

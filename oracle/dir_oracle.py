@@ -9,6 +9,8 @@ PyTorch-CPU / NumPy, with no dependency on /root/reference at run time:
     resnet_features      dirtorch/nets/backbones/resnet.py:157-174 (ResNet.forward),
                          :67-87 (Bottleneck.forward), :29-44 (BasicBlock.forward), :134-141
     rmac_forward         dirtorch/nets/rmac_resnet.py:39-69 (ResNet_RMAC.forward)
+    fpn_forward          dirtorch/nets/rmac_resnet_fpn.py:50-86 (ResNet_RMAC_FPN.forward)
+    classifier_forward   dirtorch/nets/backbones/resnet.py:157-174 with fc_out > 0
     gem_pool             dirtorch/nets/layers/pooling.py:38-40
     pool                 dirtorch/utils/common.py:41-55
     whiten_features      dirtorch/utils/common.py:221-239
@@ -72,7 +74,7 @@ def _rng(seed, key):
     return np.random.RandomState(int.from_bytes(h[:4], 'little'))
 
 
-def synth_state_dict(arch, seed=0, out_dim=2048, gemp=2.7, pooling='gem'):
+def synth_state_dict(arch, seed=0, out_dim=2048, gemp=2.7, pooling='gem', head='rmac'):
     """Deterministic per-key weights: identical wherever they are generated (golden script, tests,
     GPU box).  He-normal convs as reset_weights (resnet.py:92-99) but NON-trivial BatchNorm
     statistics, a non-integer GeM exponent, and a damped last BN per block so that activations
@@ -91,7 +93,17 @@ def synth_state_dict(arch, seed=0, out_dim=2048, gemp=2.7, pooling='gem'):
         sd[bn + '.running_mean'] = torch.from_numpy((r.standard_normal(cout) * 0.1).astype(np.float32))
         sd[bn + '.running_var'] = torch.from_numpy(r.uniform(0.6, 1.6, cout).astype(np.float32))
         sd[bn + '.num_batches_tracked'] = torch.tensor(1, dtype=torch.long)
-    if pooling.startswith('gem'):
+    if head in ('fpn', 'fpn0'):   # rmac_resnet_fpn.py:24-46 (state-dict order of the module)
+        dim1, dim2 = feat // 2, feat
+        if head == 'fpn':
+            for key, shape in (('conv1x5.weight', (dim1, dim2, 1, 1)), ('conv3c4.weight', (dim1, dim1, 3, 3))):
+                n = shape[2] * shape[3] * shape[0]
+                sd[key] = torch.from_numpy(
+                    (_rng(seed, key).standard_normal(shape) * math.sqrt(2. / n)).astype(np.float32))
+        sd['adpoolx5.p'] = torch.ones(1) * gemp
+        sd['adpoolc4.p'] = torch.ones(1) * (gemp + 0.4)
+        feat = dim1 + dim2
+    elif head == 'rmac' and pooling.startswith('gem'):
         sd['adpool.p'] = torch.ones(1) * gemp
     r = _rng(seed, 'fc')
     bound = 1. / math.sqrt(feat)
@@ -141,8 +153,9 @@ def _conv_bn(sd, x, wkey, bn, stride, pad, quant):
 
 
 # ---- trunk ----------------------------------------------------------------------------------------
-def resnet_features(sd, arch, x, quant=None):
-    """ResNet.forward up to layer4 (fc_out == 0 for *_rmac): [B,3,H,W] -> [B,C,h,w] fp32."""
+def resnet_features(sd, arch, x, quant=None, with_x4=False):
+    """ResNet.forward up to layer4 (fc_out == 0 for *_rmac): [B,3,H,W] -> [B,C,h,w] fp32.
+    with_x4 = the out_layer == -1 form (resnet.py:166-167): returns (layer3 map, layer4 map)."""
     bottleneck, layers = ARCH[arch]
     x = _q(x.float(), quant)
     x = _q(F.relu(_conv_bn(sd, x, 'conv1.weight', 'bn1', 2, 3, quant)), quant)
@@ -166,7 +179,9 @@ def resnet_features(sd, arch, x, quant=None):
                                        stride, 0, quant), quant)
             x = _q(F.relu(out + residual), quant)
             inplanes = planes * exp
-    return x
+        if s == 2:
+            x4 = x
+    return (x4, x) if with_x4 else x
 
 
 def gem_pool(x, p, eps=1e-6):
@@ -208,6 +223,36 @@ def rmac_forward(sd, arch, x, pooling='gem', norm_features=False, center_bias=0,
     with torch.no_grad():
         feat = resnet_features(sd, arch, x, quant)
         return rmac_head(sd, feat, pooling, norm_features, center_bias, without_fc)
+
+
+def fpn_forward(sd, arch, x, mode=1, norm_features=False, without_fc=False, quant=None):
+    """ResNet_RMAC_FPN.forward (rmac_resnet_fpn.py:50-86), eval mode, pooling 'gem':
+    returns [B,D], or [D] when B == 1."""
+    with torch.no_grad():
+        x4, x5 = resnet_features(sd, arch, x, quant, with_x4=True)
+        if mode == 1:
+            c5 = F.interpolate(x5, size=x4.shape[-2:], mode='nearest')
+            c5 = _q(F.relu(F.conv2d(c5, _q(sd['conv1x5.weight'].float(), quant))), quant)
+            x4 = _q(x4 + c5, quant)
+            x4 = _q(F.relu(F.conv2d(x4, _q(sd['conv3c4.weight'].float(), quant), padding=1)), quant)
+        p5 = gem_pool(x5, sd['adpoolx5.p'].float())
+        p4 = gem_pool(x4, sd['adpoolc4.p'].float())
+        v = torch.cat((p4, p5), 1)
+        if norm_features:
+            v = F.normalize(v, p=2, dim=1)
+        v = v.squeeze()
+        if not without_fc:
+            v = F.linear(v, sd['fc.weight'].float(), sd['fc.bias'].float())
+        return F.normalize(v, p=2, dim=-1)
+
+
+def classifier_forward(sd, arch, x, quant=None):
+    """Plain ResNet.forward with fc_out > 0 (resnet.py:157-174): average pool + FC, [B, fc_out]."""
+    with torch.no_grad():
+        feat = resnet_features(sd, arch, x, quant)
+        v = F.adaptive_avg_pool2d(feat, 1)
+        v = v.view(v.size(0), -1)
+        return F.linear(v, sd['fc.weight'].float(), sd['fc.bias'].float())
 
 
 # ---- post-processing --------------------------------------------------------------------------------

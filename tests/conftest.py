@@ -25,3 +25,9 @@ def model_goldens():
 def postproc_goldens():
     import numpy as np
     return np.load(os.path.join(GOLDEN, 'postproc_goldens.npz'), allow_pickle=True)
+
+
+@pytest.fixture(scope='session')
+def head_goldens():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, 'head_goldens.npz'))

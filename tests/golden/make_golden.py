@@ -2,11 +2,12 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py
+    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py [model] [head] [postproc]
 
 What is pinned (reference file:line):
     descriptors      dirtorch.nets.create_model(...)(x)      nets/__init__.py:24, rmac_resnet.py:39-69
     trunk features   ResNet.forward                          backbones/resnet.py:157-174
+    FPN / classifier create_model('*_fpn_rmac' | 'resnetNN')(x)  rmac_resnet_fpn.py:50-86, resnet.py:157-174
     pool             dirtorch.utils.common.pool              utils/common.py:41-55
     whiten_features  dirtorch.utils.common.whiten_features   utils/common.py:221-239  (sklearn PCA)
     matmul           dirtorch.utils.common.matmul            utils/common.py:30-38
@@ -72,6 +73,37 @@ def model_goldens():
     np.savez_compressed(os.path.join(HERE, 'model_goldens.npz'), **out)
 
 
+# (tag, reference factory name, oracle head, arch, model options, B, H, W)
+HEAD_CASES = [
+    ('r50_fpn', 'resnet50_fpn_rmac', 'fpn', 'resnet50', dict(), 2, 97, 75),       # 4x3 -> 7x5 upsample
+    ('r18_fpn_norm', 'resnet18_fpn_rmac', 'fpn', 'resnet18', dict(norm_features=True), 2, 96, 80),
+    ('r50_fpn_b1', 'resnet50_fpn_rmac', 'fpn', 'resnet50', dict(out_dim=512), 1, 64, 64),
+    ('r50_fpn_nofc', 'resnet50_fpn_rmac', 'fpn', 'resnet50', dict(without_fc=True), 2, 64, 96),
+    ('r101_fpn0', 'resnet101_fpn0_rmac', 'fpn0', 'resnet101', dict(), 1, 128, 96),
+    ('r50_cls', 'resnet50', 'cls', 'resnet50', dict(out_dim=1000), 2, 64, 80),
+    ('r18_cls_b1', 'resnet18', 'cls', 'resnet18', dict(out_dim=256), 1, 64, 64),
+]
+
+
+def head_goldens():
+    """The FPN heads (rmac_resnet_fpn.py:50-86) and the plain classifier (resnet.py:157-174)."""
+    out = {}
+    for tag, factory, head, arch, opts, B, H, W in HEAD_CASES:
+        feat = 512 * (4 if O.ARCH[arch][0] else 1)
+        default_out = feat + feat // 2 if head in ('fpn', 'fpn0') else 2048
+        sd = O.synth_state_dict(arch, seed=9, out_dim=opts.get('out_dim', default_out), gemp=2.6,
+                                pooling='gem', head=head)
+        net = ref_nets.create_model(factory, pretrained='', **opts)
+        net.load_state_dict(sd)
+        net.eval()
+        x = O.synth_images(13, B, H, W)
+        with torch.no_grad():
+            desc = net(x.clone())
+        out[tag + '.desc'] = desc.numpy()
+        print(tag, 'out', tuple(desc.shape))
+    np.savez_compressed(os.path.join(HERE, 'head_goldens.npz'), **out)
+
+
 def postproc_goldens():
     from sklearn.decomposition import PCA
     r = np.random.RandomState(3)
@@ -133,5 +165,10 @@ def postproc_goldens():
 
 
 if __name__ == '__main__':
-    model_goldens()
-    postproc_goldens()
+    which = sys.argv[1:] or ['model', 'head', 'postproc']
+    if 'model' in which:
+        model_goldens()
+    if 'head' in which:
+        head_goldens()
+    if 'postproc' in which:
+        postproc_goldens()

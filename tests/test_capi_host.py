@@ -51,8 +51,15 @@ def test_model_names_match_reference():
         nets.create_model('resnet34_rmac')
     with pytest.raises(ValueError):
         nets.create_model('resnet50_rmac', pooling='median')   # rmac_resnet.py:31
-    with pytest.raises(NotImplementedError):
-        nets.create_model('resnet50_fpn_rmac')
+    # every name instantiates (host object only; no GPU needed until forward)
+    fpn = nets.create_model('resnet50_fpn_rmac', scales=[1])
+    assert fpn.out_dim == 3072 and fpn.state_dict()['fc.weight'].shape == (3072, 3072)
+    assert fpn.state_dict()['conv1x5.weight'].shape == (1024, 2048, 1, 1)
+    assert fpn.state_dict()['conv3c4.weight'].shape == (1024, 1024, 3, 3)
+    fpn0 = nets.create_model('resnet101_fpn0_rmac')
+    assert 'conv1x5.weight' not in fpn0.state_dict() and 'adpoolc4.p' in fpn0.state_dict()
+    cls = nets.create_model('resnet18', out_dim=1000)
+    assert cls.state_dict()['fc.weight'].shape == (1000, 512) and 'adpool.p' not in cls.state_dict()
 
 
 def test_state_dict_keys_and_shapes_match_reference_layout():

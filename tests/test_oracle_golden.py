@@ -45,6 +45,45 @@ def test_descriptor_matches_reference(case, model_goldens):
     np.testing.assert_allclose(np.linalg.norm(desc.reshape(-1, desc.shape[-1]), axis=1), 1.0, atol=1e-5)
 
 
+# mirrors HEAD_CASES of tests/golden/make_golden.py
+HEAD_CASES = [
+    ('r50_fpn', 'fpn', 'resnet50', dict(), 2, 97, 75),
+    ('r18_fpn_norm', 'fpn', 'resnet18', dict(norm_features=True), 2, 96, 80),
+    ('r50_fpn_b1', 'fpn', 'resnet50', dict(out_dim=512), 1, 64, 64),
+    ('r50_fpn_nofc', 'fpn', 'resnet50', dict(without_fc=True), 2, 64, 96),
+    ('r101_fpn0', 'fpn0', 'resnet101', dict(), 1, 128, 96),
+    ('r50_cls', 'cls', 'resnet50', dict(out_dim=1000), 2, 64, 80),
+    ('r18_cls_b1', 'cls', 'resnet18', dict(out_dim=256), 1, 64, 64),
+]
+
+
+def head_case_inputs(tag, head, arch, opts, B, H, W):
+    feat = 512 * (4 if O.ARCH[arch][0] else 1)
+    default_out = feat + feat // 2 if head in ('fpn', 'fpn0') else 2048
+    sd = O.synth_state_dict(arch, seed=9, out_dim=opts.get('out_dim', default_out), gemp=2.6,
+                            pooling='gem', head=head)
+    return sd, O.synth_images(13, B, H, W)
+
+
+def head_oracle(sd, head, arch, opts, x, quant=None):
+    if head == 'cls':
+        return O.classifier_forward(sd, arch, x, quant=quant)
+    kw = {k: v for k, v in opts.items() if k != 'out_dim'}
+    return O.fpn_forward(sd, arch, x, mode=1 if head == 'fpn' else 0, quant=quant, **kw)
+
+
+@pytest.mark.parametrize('case', HEAD_CASES, ids=[c[0] for c in HEAD_CASES])
+def test_fpn_and_classifier_match_reference(case, head_goldens):
+    tag, head, arch, opts, B, H, W = case
+    sd, x = head_case_inputs(*case)
+    got = head_oracle(sd, head, arch, opts, x).numpy()
+    gold = head_goldens[tag + '.desc']
+    assert got.shape == gold.shape      # FPN squeezes at B == 1, the classifier keeps [1, out]
+    scale = max(1.0, np.abs(gold).max())
+    assert np.abs(got - gold).max() < 2e-6 * scale
+    assert np.all(O.cosine(got, gold) > 1 - 1e-9)
+
+
 def test_folded_bn_equals_unfolded():
     # the engine folds BatchNorm into the conv; the oracle's quant path does too - both must agree
     sd = O.synth_state_dict('resnet18', seed=3)
