@@ -321,6 +321,25 @@ int dir_global_pool(const void* x, float* out, int B, int H, int W, int C, int p
     DIR_CATCH
 }
 
+int dir_resize_workspace_bytes(int B, int H, int W, int OH, int OW, size_t* bytes) {
+    DIR_TRY
+    if (!bytes || B <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0)
+        return fail(DIR_ERR_INVALID, "resize_workspace_bytes: bad argument");
+    *bytes = resize_workspace_bytes(B, H, W, OH, OW);
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_resize_bilinear_u8(const void* src, void* dst, int B, int H, int W, int OH, int OW, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    DIR_TRY
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0)
+        return fail(DIR_ERR_INVALID, "resize_bilinear_u8: bad argument");
+    return resize_bilinear_u8((const uint8_t*)src, (uint8_t*)dst, B, H, W, OH, OW, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
                      int dtype, void* stream) {
     DIR_TRY

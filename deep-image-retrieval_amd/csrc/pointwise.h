@@ -13,6 +13,9 @@ int global_pool(const void* x, float* out, int ldo, int B, int H, int W, int C, 
 int upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
                  int dtype, hipStream_t stream);
 int l2norm_rows(float* x, int rows, int cols, float eps, hipStream_t stream);
+size_t resize_workspace_bytes(int B, int H, int W, int OH, int OW);
+int resize_bilinear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int OH, int OW, void* ws,
+                       size_t ws_bytes, hipStream_t stream);
 int multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                     hipStream_t stream);
 int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,

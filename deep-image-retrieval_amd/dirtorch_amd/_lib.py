@@ -72,6 +72,9 @@ SIGNATURES = {
     'dir_maxpool_3x3s2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dir_global_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                 c_float, c_float, c_int, c_void_p]),
+    'dir_resize_workspace_bytes': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    'dir_resize_bilinear_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_size_t, c_void_p]),
     'dir_upsample_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p]),
     'dir_l2norm_rows': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -94,9 +94,10 @@ class SubDataset(object):
         return self.dataset.get_label(self.lo + i, *a, **k)
 
 
-def extract_sharded(extract_fn, dataset, trfs, net, **kw):
+def extract_sharded(extract_fn, dataset, trfs, net, width=None, **kw):
     """extract_fn(dataset, trfs, net, **kw) -> [N, D]; under torch.distributed each rank runs it on
-    its own shard and the blocks are all-gathered."""
+    its own shard and the blocks are all-gathered.  `width`: row length when it is not the network's
+    descriptor size (the fused multi-scale extraction returns the scales side by side)."""
     if world_size() == 1:
         return extract_fn(dataset, trfs, net, **kw)
     n = len(dataset)
@@ -104,6 +105,6 @@ def extract_sharded(extract_fn, dataset, trfs, net, **kw):
     if hi > lo:
         local = extract_fn(SubDataset(dataset, lo, hi), trfs, net, **kw)
     else:
-        D = net.trunk_dim if getattr(net, 'without_fc', False) else net.out_dim
+        D = width or (net._head_in_dim() if getattr(net, 'without_fc', False) else net.out_dim)
         local = torch.empty((0, D), dtype=torch.float32, device='cuda' if net.iscuda else 'cpu')
     return allgather_rows(local, n)

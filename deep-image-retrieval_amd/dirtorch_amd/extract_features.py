@@ -30,13 +30,9 @@ def extract_features(db, net, trfs, pooling='mean', gemp=3, detailed=False, whit
         query_db = None
     separate_queries = query_db is not None and query_db is not db
 
-    per_scale = {'db': [], 'q': []}
-    for chain in ([trfs] if isinstance(trfs, str) else trfs):
-        kw = dict(iscuda=net.iscuda, threads=threads, batch_size=batch_size,
-                  same_size='Pad' in chain or 'Crop' in chain)
-        per_scale['db'].append(ddist.extract_sharded(test.extract_image_features, db, chain, net, desc="DB", **kw))
-        if separate_queries:
-            per_scale['q'].append(test.extract_image_features(query_db, chain, net, desc="query", **kw))
+    kw = dict(threads=threads, batch_size=batch_size)
+    per_scale = {'db': test.extract_per_scale(db, trfs, net, desc="DB", sharded=True, **kw),
+                 'q': test.extract_per_scale(query_db, trfs, net, desc="query", **kw) if separate_queries else []}
 
     def finish(descs):
         descs = tonumpy(common.l2_normalize(pool(descs, pooling, gemp)))

@@ -120,6 +120,24 @@ def global_pool(x, pooling='gem', p=3.0, eps=1e-6, center_bias=0.0):
     return out
 
 
+def resize_bilinear_u8(img, size):
+    """PIL `img.resize((ow, oh), Image.BILINEAR)` of uint8 images on the GPU, bit-identical to Pillow.
+    img: [H,W,3] or [B,H,W,3] uint8; size = (ow, oh) like PIL.  The `Scale` transform of
+    dirtorch/utils/transforms.py:133-185 without the CPU."""
+    _need_cuda(img)
+    if img.dtype != torch.uint8 or img.shape[-1] != 3 or img.dim() not in (3, 4):
+        raise TypeError('uint8 [H,W,3] or [B,H,W,3] image expected')
+    x = img.contiguous().view((-1,) + tuple(img.shape[-3:]))
+    B, H, W, _ = x.shape
+    ow, oh = int(size[0]), int(size[1])
+    need = ctypes.c_size_t()
+    call('dir_resize_workspace_bytes', B, H, W, oh, ow, ctypes.byref(need))
+    ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+    out = torch.empty(B, oh, ow, 3, dtype=torch.uint8, device=x.device)
+    call('dir_resize_bilinear_u8', ptr(x), ptr(out), B, H, W, oh, ow, ptr(ws), ws.numel(), stream_ptr())
+    return out if img.dim() == 4 else out[0]
+
+
 def upsample_add(x, low):
     """x + nearest-upsampled low: NHWC 16-bit [B,H,W,C] and [B,h,w,C] (rmac_resnet_fpn.py:55-60)."""
     _need_cuda(x, low)

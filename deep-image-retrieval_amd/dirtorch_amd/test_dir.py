@@ -27,6 +27,7 @@ from . import nets
 from .utils import common
 from .utils.common import matmul, pool, tonumpy
 from .utils.convenient import mkdir
+from .utils import transforms as trf_mod
 from .utils.pytorch_loader import get_loader
 
 
@@ -77,6 +78,49 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
     return (torch.cat(kept, dim=0) if same_size else kept), feats
 
 
+def extract_multiscale_features(dataset, scales, net, desc="Extract feats...", iscuda=True, threads=8):
+    """All scales of a multi-scale run from ONE decode and ONE upload per image: the raw uint8
+    picture goes to the GPU, each `Scale` (None = original size) is applied there with the
+    Pillow-identical resize kernel, and the network runs once per scale.  Returns [N, S*D], the
+    per-scale descriptors side by side - the same values as S passes of extract_image_features with
+    the chains 'Scale(..)' (test_dir.py:47-94, 118-122), which decode and resize S times on the CPU."""
+    from . import ops
+    loader = get_loader(dataset, trf_chain='', preprocess=net.preprocess, iscuda=iscuda,
+                        output=['img'], batch_size=1, threads=threads, shuffle=False)
+    net.eval()
+    rows = []
+    with torch.no_grad():
+        for (img,) in tqdm.tqdm(loader, desc, total=len(dataset)):
+            img = common.variables([img], net.iscuda)[0]              # [1, H, W, 3] uint8
+            H, W = int(img.shape[1]), int(img.shape[2])
+            per_scale = []
+            for sc in scales:
+                size = (W, H) if sc is None else sc.target_size((W, H))
+                x = img if size == (W, H) else ops.resize_bilinear_u8(img, size)
+                per_scale.append(net(x).reshape(1, -1))
+            rows.append(torch.cat(per_scale, dim=1))
+    return torch.cat(rows, dim=0)
+
+
+def extract_per_scale(dataset, trfs, net, desc, threads=8, batch_size=16, sharded=False):
+    """One [N, D] descriptor tensor per transform chain of `trfs` (a string or a list of strings,
+    test_dir.py:118-120).  `sharded`: split the images over the torch.distributed ranks and
+    all-gather (dirtorch_amd.distributed); otherwise every rank extracts the whole set."""
+    chains = [trfs] if isinstance(trfs, str) else list(trfs)
+    run = ddist.extract_sharded if sharded else (lambda fn, ds, arg, net, width=None, **kw: fn(ds, arg, net, **kw))
+    scales = None
+    if os.environ.get('DIRTORCH_AMD_DEVICE_SCALE', '1') != '0' and net.iscuda:
+        scales = trf_mod.device_scales(chains, **net.preprocess)
+    if scales is not None and any(s is not None for s in scales):
+        # every chain is '' or one Scale(..): decode + upload once, resize per scale on the GPU
+        D = net._head_in_dim() if net.without_fc else net.out_dim
+        fused = run(extract_multiscale_features, dataset, scales, net, width=len(scales) * D, desc=desc,
+                    iscuda=net.iscuda, threads=threads)
+        return list(fused.split(D, dim=1))
+    return [run(extract_image_features, dataset, chain, net, desc=desc, iscuda=net.iscuda, threads=threads,
+                batch_size=batch_size, same_size='Pad' in chain or 'Crop' in chain) for chain in chains]
+
+
 def _mean_ap(aps, detailed, res):
     """Aggregate per-query APs the way test_dir.py:154-167 does: queries whose AP is -1 (no relevant
     image in that mode) are left out of the mean."""
@@ -106,14 +150,9 @@ def eval_model(db, net, trfs, pooling='mean', gemp=3, detailed=False, whiten=Non
         bdescs = np.load(os.path.join(load_feats, 'feats.bdescs.npy'))
         qdescs = bdescs if same_set else np.load(os.path.join(load_feats, 'feats.qdescs.npy'))
     else:
-        per_scale_b, per_scale_q = [], []
-        for chain in ([trfs] if isinstance(trfs, str) else trfs):
-            kw = dict(iscuda=net.iscuda, threads=threads, batch_size=batch_size,
-                      same_size='Pad' in chain or 'Crop' in chain)
-            # image-parallel shards + one all-gather when torch.distributed is initialised
-            per_scale_b.append(ddist.extract_sharded(extract_image_features, db, chain, net, desc="DB", **kw))
-            per_scale_q.append(per_scale_b[-1] if same_set else
-                               extract_image_features(query_db, chain, net, desc="query", **kw))
+        kw = dict(threads=threads, batch_size=batch_size)
+        per_scale_b = extract_per_scale(db, trfs, net, desc="DB", sharded=True, **kw)
+        per_scale_q = per_scale_b if same_set else extract_per_scale(query_db, trfs, net, desc="query", **kw)
         bdescs = common.l2_normalize(pool(per_scale_b, pooling, gemp))    # multi-scale pooling, then L2
         qdescs = common.l2_normalize(pool(per_scale_q, pooling, gemp))
 

@@ -41,12 +41,18 @@ class Scale(object):
             return int(0.5 + self.size * w), int(0.5 + self.size * h)
         return tuple(self.size)
 
+    def target_size(self, imsize):
+        """(w, h) the image has after this transform, honouring can_upscale / can_downscale."""
+        imsize = tuple(imsize)
+        size2 = tuple(self.get_params(imsize))
+        grows, shrinks = min(imsize) < min(size2), min(imsize) > min(size2)
+        if size2 != imsize and ((self.can_upscale and grows) or (self.can_downscale and shrinks)):
+            return size2
+        return imsize
+
     def __call__(self, img):
-        size2 = self.get_params(img.size)
-        if size2 != img.size:
-            if (self.can_upscale and min(img.size) < min(size2)) or (self.can_downscale and min(img.size) > min(size2)):
-                img = img.resize(size2, self.interpolation)
-        return img
+        size2 = self.target_size(img.size)
+        return img if size2 == img.size else img.resize(size2, self.interpolation)
 
 
 class Pad(object):
@@ -128,6 +134,22 @@ class Compose(object):
         for t in self.transforms:
             x = t(x)
         return x
+
+
+def device_scales(chains, **vars):
+    """If every chain of `chains` is empty or one bilinear Scale(...), the list of those Scale
+    objects (None for an empty chain): such chains can be run as ONE decode + upload per image and a
+    bit-identical resize per scale on the GPU (ops.resize_bilinear_u8).  Otherwise None."""
+    out = []
+    for chain in chains:
+        trfs = create(chain, to_tensor=False, **vars).transforms
+        if len(trfs) == 0:
+            out.append(None)
+        elif len(trfs) == 1 and isinstance(trfs[0], Scale) and trfs[0].interpolation == Image.BILINEAR:
+            out.append(trfs[0])
+        else:
+            return None
+    return out
 
 
 _ALLOWED = {c.__name__: c for c in (Scale, Pad, PadSquare, CenterCrop, ToTensor, Normalize)}

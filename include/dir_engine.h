@@ -160,6 +160,14 @@ int dir_prep_input(const void* img, int img_format, const float* mean3, const fl
  * output size the pool runs over.  What dir_forward uses. */
 int dir_stem_pool(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
                   int OH, int OW, int dtype, void* stream);
+/* The `Scale` test-time transform (dirtorch/utils/transforms.py:133-185 -> PIL
+ * Image.resize(size, BILINEAR)) for uint8 NHWC RGB images already on the device: Pillow's
+ * antialiased triangle filter with 22-bit fixed-point weights, horizontal then vertical pass, each
+ * rounded to uint8 - bit-identical to Pillow (src/libImaging/Resample.c).  All B images share H x W.
+ * workspace: dir_resize_workspace_bytes() bytes, 4-byte aligned; three async launches on `stream`. */
+int dir_resize_workspace_bytes(int B, int H, int W, int OH, int OW, size_t* bytes);
+int dir_resize_bilinear_u8(const void* src, void* dst, int B, int H, int W, int OH, int OW,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* K3: MaxPool2d(3, stride 2, pad 1) on NHWC (dirtorch/nets/backbones/resnet.py:119). */
 int dir_maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 /* K8: global pooling over H*W of NHWC x -> fp32 [B,C] (dirtorch/nets/layers/pooling.py:38-40);

@@ -12,6 +12,7 @@ PyTorch-CPU / NumPy, with no dependency on /root/reference at run time:
     fpn_forward          dirtorch/nets/rmac_resnet_fpn.py:50-86 (ResNet_RMAC_FPN.forward)
     classifier_forward   dirtorch/nets/backbones/resnet.py:157-174 with fc_out > 0
     gem_pool             dirtorch/nets/layers/pooling.py:38-40
+    resize_bilinear_u8   dirtorch/utils/transforms.py:133-185 (Scale -> PIL bilinear resize)
     pool                 dirtorch/utils/common.py:41-55
     whiten_features      dirtorch/utils/common.py:221-239
     matmul               dirtorch/utils/common.py:30-38
@@ -253,6 +254,62 @@ def classifier_forward(sd, arch, x, quant=None):
         v = F.adaptive_avg_pool2d(feat, 1)
         v = v.view(v.size(0), -1)
         return F.linear(v, sd['fc.weight'].float(), sd['fc.bias'].float())
+
+
+# ---- Scale (PIL bilinear resize of an 8-bit RGB image) ----------------------------------------------
+# dirtorch/utils/transforms.py:133-185 calls img.resize(size, Image.BILINEAR).  The arithmetic lives
+# in Pillow (unpinned by the reference; 12.2.0 here): src/libImaging/Resample.c, restated below -
+# precompute_coeffs (triangle filter, support scaled by max(in/out, 1)), normalize_coeffs_8bpc
+# (22-bit fixed point), then a horizontal and a vertical pass that each round to uint8.
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """(xmin[out], count[out], kk[out, ksize] int32) for one axis, box = the whole image."""
+    scale = float(in_size) / float(out_size)
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = 0.0 + (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    ss = 1.0 / filterscale
+    xmin = np.maximum(np.trunc(center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum(np.trunc(center + support + 0.5).astype(np.int64), in_size) - xmin
+    k = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):
+        arg = np.abs((x + xmin - center + 0.5) * ss)
+        w = np.where(arg < 1.0, 1.0 - arg, 0.0)
+        w = np.where(x < xmax, w, 0.0)
+        k[:, x] = w
+        ww = ww + w
+    nz = ww != 0.0
+    k[nz] = k[nz] / ww[nz, None]
+    kk = np.trunc(np.where(k < 0, -0.5, 0.5) + k * float(1 << PIL_PRECISION_BITS)).astype(np.int32)
+    return xmin.astype(np.int32), xmax.astype(np.int32), kk
+
+
+def _pil_resample_axis(img, out_size, axis):
+    """One 8-bit pass of ImagingResampleHorizontal/Vertical_8bpc along `axis` of an HWC array."""
+    xmin, cnt, kk = pil_bilinear_coeffs(img.shape[axis], out_size)
+    a = np.moveaxis(img, axis, 0).astype(np.int64)
+    acc = np.full((out_size,) + a.shape[1:], 1 << (PIL_PRECISION_BITS - 1), dtype=np.int64)
+    for x in range(kk.shape[1]):
+        idx = np.minimum(xmin + x, a.shape[0] - 1)          # taps past the count carry weight 0
+        wgt = np.where(x < cnt, kk[:, x], 0).astype(np.int64)
+        acc += a[idx] * wgt.reshape((-1,) + (1,) * (a.ndim - 1))
+    out = np.clip(acc >> PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def resize_bilinear_u8(img, ow, oh):
+    """PIL.Image.resize((ow, oh), Image.BILINEAR) of a uint8 HWC image; a pass whose size does not
+    change is skipped, as ImagingResample does."""
+    img = np.ascontiguousarray(img)
+    if ow != img.shape[1]:
+        img = _pil_resample_axis(img, ow, 1)
+    if oh != img.shape[0]:
+        img = _pil_resample_axis(img, oh, 0)
+    return img
 
 
 # ---- post-processing --------------------------------------------------------------------------------

@@ -107,6 +107,22 @@ def test_quant_emulation_is_close():
         assert np.all(1 - O.cosine(got, ref) < tol), (q, 1 - O.cosine(got, ref))
 
 
+RESIZE_CASES = [(37, 53, 52, 75), (64, 64, 45, 45), (120, 90, 170, 127), (100, 100, 100, 141),
+                (50, 70, 50, 35), (33, 47, 11, 13), (200, 300, 71, 424), (17, 19, 68, 76), (10, 10, 1, 1),
+                (5, 7, 500, 3), (96, 128, 96, 128), (240, 320, 339, 452), (240, 320, 170, 226)]
+
+
+@pytest.mark.parametrize('shape', RESIZE_CASES, ids=['%dx%d_to_%dx%d' % c for c in RESIZE_CASES])
+def test_resize_restatement_is_bit_identical_to_pillow(shape):
+    """The Scale transform (transforms.py:133-185) delegates to Pillow, which is the pin here."""
+    from PIL import Image
+    h, w, oh, ow = shape
+    img = np.random.RandomState(h * 1000 + ow).randint(0, 256, (h, w, 3)).astype(np.uint8)
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    got = O.resize_bilinear_u8(img, ow, oh)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
 def test_pool(postproc_goldens):
     g = postproc_goldens
     xs = [torch.from_numpy(a) for a in g['pool.in']]

@@ -184,3 +184,52 @@ def test_extract_whiten_rank_map_parity(dtype, tol_w, tol_map):
     for k in m_ref:
         assert abs(m_ref[k] - m_got[k]) < tol_map, (k, m_ref[k], m_got[k])
     assert m_ref['mAP-easy'] > 0.5        # the planted structure is actually retrievable
+
+
+def test_multiscale_device_resize_equals_cpu_pil_path(tmp_path, monkeypatch):
+    """--trfs with several Scale(..) chains: the fused path (decode + upload once, Pillow-identical
+    resize on the GPU) must give the very same file as one PIL-resizing loader pass per scale, and
+    both must match the oracle run over PIL-resized images + common.pool (test_dir.py:118-122)."""
+    import dir_oracle as O
+    from PIL import Image
+    from dirtorch_amd import extract_features as ef
+    names = ['a.png', 'b.png', 'c.png', 'd.png']
+    sizes = [(96, 128), (130, 90), (75, 101), (64, 112)]
+    save_images(str(tmp_path / 'imgs'), names, sizes, 3)
+    (tmp_path / 'list.txt').write_text('\n'.join(names) + '\n')
+    sd = O.synth_state_dict('resnet18', seed=7, gemp=3.0)
+    ck = str(tmp_path / 'synth.pt')
+    make_checkpoint(ck, 'resnet18', sd, fitted_pca())
+    monkeypatch.setenv('DIRTORCH_AMD_DTYPE', 'fp16')
+    chains = ['', 'Scale(1.414)', 'Scale(0.707)']
+    outs = {}
+    for pooling in ('mean', 'gem'):
+        for flag in ('1', '0'):
+            monkeypatch.setenv('DIRTORCH_AMD_DEVICE_SCALE', flag)
+            out = str(tmp_path / ('ms_%s_%s.npy' % (pooling, flag)))
+            argv = ['--dataset', 'ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'),
+                    '--checkpoint', ck, '--output', out, '--gpu', '0', '--threads', '0', '--pooling', pooling,
+                    '--gemp', '3', '--trfs'] + chains
+            ef.main(argv)
+            outs[pooling, flag] = np.load(out)
+        # bit-identical resize -> bit-identical descriptors
+        assert np.array_equal(outs[pooling, '1'], outs[pooling, '0'])
+
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    per_scale = []
+    for f in (0, 1.414, 0.707):
+        rows = []
+        for n in names:
+            img = Image.open(str(tmp_path / 'imgs' / n)).convert('RGB')
+            if f:
+                img = img.resize((int(0.5 + f * img.size[0]), int(0.5 + f * img.size[1])), Image.BILINEAR)
+            x = (torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255 - mean) / std
+            rows.append(O.rmac_forward(sd, 'resnet18', x[None]).reshape(1, -1))
+        per_scale.append(torch.cat(rows, 0))
+    # the signed cube root of 'gem' is ill-conditioned where the scales cancel (d/dx x^(1/3) -> inf
+    # at 0), so fp16-level input error shows up as ~1e-4; 'mean' is the tight gate
+    for pooling, tol in (('mean', 1e-4), ('gem', 2e-3)):
+        ref = torch.nn.functional.normalize(O.pool(per_scale, pooling, 3), dim=1).numpy()
+        err = 1 - O.cosine(outs[pooling, '1'], ref)
+        assert np.all(err < tol), (pooling, err)
