@@ -368,6 +368,39 @@ int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out
     DIR_CATCH
 }
 
+int dir_fc_l2(const float* x, int B, int K, const float* W, const float* b, int D, float* out,
+              void* stream) {
+    DIR_TRY
+    if (!x || !W || !out || B <= 0 || K <= 0 || D <= 0) return fail(DIR_ERR_INVALID, "fc_l2: bad argument");
+    int rc = gemm_nt_f32(W, K, x, K, out, D, D, B, K, nullptr, b, nullptr, (hipStream_t)stream);
+    if (rc != DIR_OK) return rc;
+    return l2norm_rows(out, B, D, 1e-12f, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components, int v,
+                      const float* scale, int l2norm, float* out, void* stream) {
+    DIR_TRY
+    if (N < 0 || D <= 0 || v <= 0) return fail(DIR_ERR_INVALID, "pca_whiten_l2: bad size");
+    if (N == 0) return DIR_OK;
+    if (!X || !components || !out) return fail(DIR_ERR_INVALID, "pca_whiten_l2: null pointer");
+    int rc = gemm_nt_f32(components, D, X, D, out, v, v, N, D, mean, nullptr, scale, (hipStream_t)stream);
+    if (rc != DIR_OK || !l2norm) return rc;
+    return l2norm_rows(out, N, v, 1e-12f, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_similarity(const float* queries, int Q, const float* database, int N, int D, float* scores,
+                   void* stream) {
+    DIR_TRY
+    if (Q < 0 || N < 0 || D <= 0) return fail(DIR_ERR_INVALID, "similarity: bad size");
+    if (Q == 0 || N == 0) return DIR_OK;
+    if (!queries || !database || !scores) return fail(DIR_ERR_INVALID, "similarity: null pointer");
+    return gemm_nt_f32(database, D, queries, D, scores, N, N, Q, D, nullptr, nullptr, nullptr,
+                       (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P,
                     int* counts, float* probe_scores, void* stream) {
     DIR_TRY

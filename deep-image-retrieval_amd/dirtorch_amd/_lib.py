@@ -80,6 +80,10 @@ SIGNATURES = {
     'dir_l2norm_rows': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     'dir_gemm_nt_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dir_fc_l2': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'dir_pca_whiten_l2': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p]),
+    'dir_similarity': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dir_rank_counts': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     'dir_multiscale_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,

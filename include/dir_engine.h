@@ -191,6 +191,22 @@ int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream);
 int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo,
                     int NP, int NQ, int K, const float* qsub, const float* bias,
                     const float* alpha, void* stream);
+/* The three named uses of the GEMM above, as the reference's callers see them (all fp32, row-major,
+ * contiguous; every output buffer is the caller's):
+ *   dir_fc_l2          x[B,K] -> normalize(x W^T + b): the tail of ResNet_RMAC.forward
+ *                      (dirtorch/nets/rmac_resnet.py:66-68); W is [D,K] (nn.Linear layout)
+ *   dir_pca_whiten_l2  common.whiten_features (dirtorch/utils/common.py:221-239):
+ *                      out[n][i] = scale[i] * sum_k components[i][k] * (X[n][k] - mean[k]), i < v, then
+ *                      row L2 if l2norm != 0; scale[i] = 1 / (whitenm * explained_variance[i]^whitenp)
+ *                      is computed by the caller (v floats, device), NULL = no rescaling
+ *   dir_similarity     common.matmul(queries, database) (dirtorch/utils/common.py:30-38):
+ *                      scores[q][n] = <queries[q], database[n]>, scores is [Q,N] with row stride N */
+int dir_fc_l2(const float* x, int B, int K, const float* W, const float* b, int D, float* out,
+              void* stream);
+int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components,
+                      int v, const float* scale, int l2norm, float* out, void* stream);
+int dir_similarity(const float* queries, int Q, const float* database, int N, int D, float* scores,
+                   void* stream);
 /* K10: multi-scale pooling of S descriptor sets [S][N][D] -> [N][D] (common.py:41-55):
  * mode 0 = mean, 1 = signed-power ("gem") mean with exponent gemp; no final L2 (caller does it). */
 int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,

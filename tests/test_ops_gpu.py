@@ -304,6 +304,34 @@ def test_common_postproc_vs_reference_goldens(postproc_goldens):
         common.matmul(torch.from_numpy(g['matmul.A']), g['matmul.B'])
 
 
+def test_named_entry_points_vs_reference_goldens(postproc_goldens):
+    """dir_pca_whiten_l2 / dir_similarity / dir_fc_l2 called straight through the C ABI (what a
+    non-Python host would bind) against the reference's own whiten_features / matmul outputs."""
+    from dirtorch_amd._lib import call, ptr, stream_ptr
+    g = postproc_goldens
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    X, mean, comps, var = dev(g['whiten.in']), dev(g['pca.mean']), dev(g['pca.components']), g['pca.var']
+    N, D = X.shape
+    for key, v, p, m, l2 in (('whiten.p0.5', D, 0.5, 1.0, 1), ('whiten.p0.25_v32_m2', 32, 0.25, 2.0, 1),
+                             ('whiten.nol2', D, 0.5, 1.0, 0)):
+        scale = dev(1.0 / (m * np.power(var[:v].astype(np.float64), p)))
+        out = torch.empty(N, v, device='cuda')
+        call('dir_pca_whiten_l2', ptr(X), N, D, ptr(mean), ptr(comps), v, ptr(scale), l2, ptr(out), stream_ptr())
+        np.testing.assert_allclose(out.cpu().numpy(), g[key], rtol=1e-4, atol=1e-4 if not l2 else 1e-5)
+    A, Bm = dev(g['matmul.A']), dev(g['matmul.B'])
+    scores = torch.empty(A.shape[0], Bm.shape[0], device='cuda')
+    call('dir_similarity', ptr(A), A.shape[0], ptr(Bm), Bm.shape[0], A.shape[1], ptr(scores), stream_ptr())
+    np.testing.assert_allclose(scores.cpu().numpy(), g['matmul.np'], rtol=1e-5, atol=1e-5)
+    # FC + L2 against torch on the CPU
+    gen = torch.Generator().manual_seed(2)
+    x, W, b = torch.randn(5, 192, generator=gen), torch.randn(64, 192, generator=gen) * 0.1, torch.randn(64, generator=gen)
+    out = torch.empty(5, 64, device='cuda')
+    xd, Wd, bd = x.cuda(), W.cuda(), b.cuda()
+    call('dir_fc_l2', ptr(xd), 5, 192, ptr(Wd), ptr(bd), 64, ptr(out), stream_ptr())
+    ref = torch.nn.functional.normalize(torch.nn.functional.linear(x, W, b), dim=1)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_similarity_ranking_at_scale_matches_oracle_map():
     """ROxford-sized ranking (70 x 4993 x 2048): identical mAP to the CPU oracle's np.dot path."""
     import dir_oracle as O
