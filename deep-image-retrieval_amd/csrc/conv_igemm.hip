@@ -28,6 +28,8 @@
 #include "dir_common.h"
 #include "conv_igemm.h"
 
+#include <string.h>
+
 namespace dir {
 
 // voffset beyond any descriptor (tensors are < 2^31 bytes): the DMA writes zeros.  2^31 cannot wrap
@@ -406,6 +408,12 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT(256, 256, 4, 2, 3, 32, "256x256_w4x2_s3_k32"),
     DIR_VARIANT(256, 128, 4, 2, 4, 32, "256x128_w4x2_s4_k32"),
     DIR_VARIANT(128, 128, 2, 2, 4, 32, "128x128_w2x2_s4_k32"),
+    // 72 KB of LDS and <= 128 VGPRs: two 512-thread workgroups share a CU, so one's epilogue
+    // overlaps the other's K loop (the memory-bound 1x1 convs of layer3/4)
+    DIR_VARIANT(256, 128, 4, 2, 3, 32, "256x128_w4x2_s3_k32"),
+    DIR_VARIANT(128, 256, 2, 4, 3, 32, "128x256_w2x4_s3_k32"),
+    DIR_VARIANT(128, 256, 2, 2, 3, 32, "128x256_w2x2_s3_k32"),   // two 256-thread workgroups per CU
+    DIR_VARIANT(128, 128, 2, 2, 3, 32, "128x128_w2x2_s3_k32"),   // 48 KB: three workgroups per CU
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
     {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
@@ -427,42 +435,45 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     return true;
 }
 
-static int find_variant(int BM, int BN, int nst) {
+static int find_variant(const char* name) {
     for (int v = 0; v < kNumVariants; ++v)
-        if (kVariants[v].BM == BM && kVariants[v].BN == BN && kVariants[v].stages == nst &&
-            kVariants[v].BK == 64 && kVariants[v].kind == 0)
-            return v;
+        if (strcmp(kVariants[v].name, name) == 0) return v;
     return -1;
 }
 
 // Heuristic used when a shape has not been autotuned (variable-size images, the reference's real
 // workload).  Distilled from the autotuner's choices on ResNet-101 at 1024^2 (profiles/
-// r01_tuned_variants_b32_1024.txt): narrow 3x3 layers take the LDS-patch kernel; K = 64 layers the
-// long 256x64 tile; wide outputs with a real K loop the 256x256 tile; everything else 128x128 - each
-// falling back to smaller pixel tiles until about three quarters of the 256 CUs get a workgroup.
+// r01_tuned_variants_b32_1024.txt):
+//   * narrow 3x3 layers (Cin 64) take the LDS-patch kernel, K = 64 layers the long 256x64 tile;
+//   * wide outputs with a real K loop (layer3/4 conv1 + conv2) the 256x256 tile;
+//   * wide outputs with a short K loop (the 256 -> 1024 conv3 of layer3, residual + store bound)
+//     and everything with 128/512 outputs (layer2) the 72 KB / 128-VGPR tiles that fit two
+//     workgroups per CU, so that one's epilogue overlaps the other's K loop;
+// each falling back to smaller pixel tiles until about three quarters of the CU slots get a tile.
 int conv_pick_variant(const ConvArgs& a) {
     for (int v = 0; v < kNumVariants; ++v)
         if (kVariants[v].kind == 1 && a.Cin == 64 && conv_variant_admissible(v, a)) return v;
     const int T = a.Ktot / 64;
-    int bm[3], bn[3], n = 0;
-    auto add = [&](int m, int c) {
-        bm[n] = m;
-        bn[n] = c;
-        ++n;
-    };
+    struct Cand { const char* name; int wg_per_cu; };
+    Cand c[4];
+    int n = 0;
     if (T <= 1 || a.Cout % 128 != 0) {
-        add(256, 64), add(128, 64), add(64, 64);
+        c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
+    } else if (a.Cout % 256 == 0 && T >= 6) {
+        c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1}, c[n++] = {"64x128_w2x2", 1};
     } else if (a.Cout % 256 == 0 && T >= 3) {
-        add(256, 256), add(128, 128), add(64, 128);
+        c[n++] = {"128x256_w2x4_s3_k32", 2}, c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
+        c[n++] = {"64x128_w2x2", 1};
     } else {
-        add(128, 128), add(64, 128);
+        c[n++] = {"256x128_w4x2_s3_k32", 2}, c[n++] = {"128x128_w2x2", 1}, c[n++] = {"64x128_w2x2", 1};
     }
     int last = -1;
     for (int i = 0; i < n; ++i) {
-        const int v = find_variant(bm[i], bn[i], 2);
+        const int v = find_variant(c[i].name);
         if (v < 0 || !conv_variant_admissible(v, a)) continue;
         last = v;
-        if ((long)ceil_div(a.M, bm[i]) * (a.Cout / bn[i]) >= 192) return v;
+        const long tiles = (long)ceil_div(a.M, kVariants[v].BM) * (a.Cout / kVariants[v].BN);
+        if (tiles >= 192L * c[i].wg_per_cu) return v;
     }
     return last;
 }

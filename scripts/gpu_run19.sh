@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B on one box: round-1 tuned table (no occupancy-2 variants) vs fresh autotune with them
+mkdir -p gpurun_out
+pick='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["all_conv_ms_per_step"])'
+cp profiles/r01_tuned_variants_b32_1024.txt /tmp/old_tune.txt
+rm -f /tmp/new_tune.txt
+for i in 1 2 3; do
+  echo -n "old "; DIRTORCH_AMD_TUNE_CACHE=/tmp/old_tune.txt timeout 600 python bench.py --cpu-seconds 0 2>/dev/null | tail -1 | python -c "$pick"
+  echo -n "new "; DIRTORCH_AMD_TUNE_CACHE=/tmp/new_tune.txt timeout 600 python bench.py --cpu-seconds 0 2>/dev/null | tail -1 | python -c "$pick"
+done
+cp /tmp/new_tune.txt gpurun_out/tune_b32_v3.txt
