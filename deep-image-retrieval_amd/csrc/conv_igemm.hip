@@ -265,12 +265,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         }
         __builtin_amdgcn_s_barrier();
         if (issued < T) {
+#ifndef DIR_EXP_NO_FILL     // experiment builds (scripts/exp_fill.sh): MFMA + fragment reads alone
             issue(issued, tap, koff_now(), smem + slot_i * STAGE_BYTES);
+#endif
             advance();
             ++issued;
             if (++slot_i == NST) slot_i = 0;
         }
+#ifndef DIR_EXP_FILL_ONLY   // experiment builds: the LDS-DMA ring alone
         compute(smem + slot_c * STAGE_BYTES);
+#endif
         if (++slot_c == NST) slot_c = 0;
     }
     __syncthreads();  // all fragment reads done before the epilogue reuses the ring
@@ -414,6 +418,9 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT(128, 256, 2, 4, 3, 32, "128x256_w2x4_s3_k32"),
     DIR_VARIANT(128, 256, 2, 2, 3, 32, "128x256_w2x2_s3_k32"),   // two 256-thread workgroups per CU
     DIR_VARIANT(128, 128, 2, 2, 3, 32, "128x128_w2x2_s3_k32"),   // 48 KB: three workgroups per CU
+    // 16 waves of 64x64 on one CU (128 VGPRs): more fragment reads in flight under the matrix
+    // pipe - the 3x3 convs of layer3/4
+    DIR_VARIANT(256, 256, 4, 4, 2, 64, "256x256_w4x4"),
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
     {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
@@ -445,7 +452,8 @@ static int find_variant(const char* name) {
 // workload).  Distilled from the autotuner's choices on ResNet-101 at 1024^2 (profiles/
 // r01_tuned_variants_b32_1024.txt):
 //   * narrow 3x3 layers (Cin 64) take the LDS-patch kernel, K = 64 layers the long 256x64 tile;
-//   * wide outputs with a real K loop (layer3/4 conv1 + conv2) the 256x256 tile;
+//   * wide outputs with a real K loop (layer3/4 conv1 + conv2) a 256x256 tile: the persistent
+//     kernel for 1x1, the 16-wave form for 3x3;
 //   * wide outputs with a short K loop (the 256 -> 1024 conv3 of layer3, residual + store bound)
 //     and everything with 128/512 outputs (layer2) the 72 KB / 128-VGPR tiles that fit two
 //     workgroups per CU, so that one's epilogue overlaps the other's K loop;
@@ -455,11 +463,13 @@ int conv_pick_variant(const ConvArgs& a) {
         if (kVariants[v].kind == 1 && a.Cin == 64 && conv_variant_admissible(v, a)) return v;
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };
-    Cand c[4];
+    Cand c[5];
     int n = 0;
     if (T <= 1 || a.Cout % 128 != 0) {
         c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     } else if (a.Cout % 256 == 0 && T >= 6) {
+        // 3x3: 16 waves of 64x64; 1x1: the persistent kernel (falls through when not admissible)
+        c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : "256x256_persist1x1", 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1}, c[n++] = {"64x128_w2x2", 1};
     } else if (a.Cout % 256 == 0 && T >= 3) {
         c[n++] = {"128x256_w2x4_s3_k32", 2}, c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};

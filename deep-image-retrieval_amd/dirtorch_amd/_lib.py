@@ -9,7 +9,8 @@ from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_float, c_i
                     c_size_t, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdir_engine.so')
+# DIRTORCH_AMD_LIB: an alternative build of the same library (kernel experiments); no other effect
+LIB_PATH = os.environ.get('DIRTORCH_AMD_LIB') or os.path.join(_HERE, 'libdir_engine.so')
 
 DIR_BF16, DIR_FP16 = 0, 1
 DIR_IMG_F32_NCHW, DIR_IMG_U8_NHWC = 0, 1
