@@ -226,19 +226,32 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     // first), (b) every wave has finished reading slot (t-1) % NST, the slot refilled right after.
     const int T = a.T;
     const int cpb = CIN16 ? 1 : (a.Cin / BK);  // K-steps per filter tap
+    // K order: channel slice outermost, filter taps innermost.  Consecutive K-steps of a 3x3 conv
+    // then read the SAME 64-channel slice of the input at pixel-shifted positions, so eight of the
+    // nine tap reads hit the XCD's L2 (a tap-major order spaced those re-reads Cin/64 steps apart,
+    // 32 CUs x that footprint overflowed the 4 MB L2 and the 3x3 layers fetched their input ~3x
+    // from the fabric - profiles/r01_bench_b32_hbm_pmc.json history).  The stem (CIN16) has one
+    // K-step per filter row and keeps row order.
     int tap = 0, cc = 0, r = 0, s = 0;         // state of the step being ISSUED
-    auto koff_now = [&]() {                    // bytes
+    auto koff_now = [&]() {                    // bytes into the input, relative to tap (0,0)
         return CIN16 ? (r * a.W * 32) : (((r * a.W + s) * a.Cin + cc * BK) * 2);
     };
+    auto wstep_now = [&]() {                   // index of this K-step's slice in a weight row
+        return CIN16 ? r : (tap * cpb + cc);
+    };
     auto advance = [&]() {
-        if (++cc == cpb) {
-            cc = 0;
+        if (CIN16) {
+            ++r;
             ++tap;
-            if (CIN16) {
-                ++r;
-            } else if (++s == a.S) {
+        } else {
+            ++tap;
+            if (++s == a.S) {
                 s = 0;
-                ++r;
+                if (++r == a.R) {
+                    r = 0;
+                    tap = 0;
+                    ++cc;
+                }
             }
         }
     };
@@ -246,7 +259,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p) {
         if (p < T) {
-            issue(p, tap, koff_now(), smem + p * STAGE_BYTES);
+            issue(wstep_now(), tap, koff_now(), smem + p * STAGE_BYTES);
             advance();
             ++issued;
         }
@@ -266,7 +279,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         __builtin_amdgcn_s_barrier();
         if (issued < T) {
 #ifndef DIR_EXP_NO_FILL     // experiment builds (scripts/exp_fill.sh): MFMA + fragment reads alone
-            issue(issued, tap, koff_now(), smem + slot_i * STAGE_BYTES);
+            issue(wstep_now(), tap, koff_now(), smem + slot_i * STAGE_BYTES);
 #endif
             advance();
             ++issued;
