@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Config E of BASELINE.md: ResNet-101 GeM, 3-scale descriptors of 1200x1200 images
+(Scale(0.7071) -> 848, original 1200, Scale(1.4142) -> 1697), everything after the decode on the GPU:
+uint8 batch resident in HBM -> Pillow-identical resize per scale -> dir_forward per scale ->
+multi-scale pooling + L2.  Reports 3-scale images/s."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'oracle')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--size', type=int, default=1200)
+    ap.add_argument('--steps', type=int, default=10)
+    args = ap.parse_args()
+    import dir_oracle as O
+    from dirtorch_amd import nets, ops
+    from dirtorch_amd.utils import common, transforms
+    net = nets.create_model('resnet101_rmac', pretrained='')
+    net.load_state_dict(O.synth_state_dict('resnet101', seed=7))
+    net.cuda().eval()
+    net.autotune = True
+    B, S = args.batch, args.size
+    img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda')
+    scales = [transforms.Scale(0.7071), None, transforms.Scale(1.4142)]
+    sizes = [(S, S) if sc is None else sc.target_size((S, S)) for sc in scales]
+
+    def step():
+        per_scale = []
+        for size in sizes:
+            x = img if size == (S, S) else ops.resize_bilinear_u8(img, size)
+            per_scale.append(net(x))
+        return common.l2_normalize(common.pool(per_scale, 'gem', 3))
+
+    step()                      # autotune every scale's shapes
+    net.autotune = False
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gflop = sum(448.76 * (s[0] / 1200.0) ** 2 for s in sizes)     # R101: 448.76 GFLOP at 1200^2
+    print(json.dumps({'workload': 'config E: resnet101_rmac, 3 scales %s of %dx%d, batch %d' % (
+        [s[0] for s in sizes], S, S, B), 'images_per_s_3scale': round(args.steps * B / el, 2),
+        'ms_per_image': round(el / (args.steps * B) * 1e3, 3),
+        'tflops': round(args.steps * B / el * gflop / 1e3, 1), 'desc_shape': list(d.shape)}))
+
+
+if __name__ == '__main__':
+    main()
