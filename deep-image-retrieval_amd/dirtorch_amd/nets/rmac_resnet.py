@@ -269,7 +269,20 @@ class ResNet_RMAC(object):
                     f.write(self.export_tuning())
         return x, B, H, W, fmt, ws
 
+    def max_batch(self, H, W):
+        """Largest batch one dir_forward call takes at H x W: every activation tensor must stay
+        below 2^31 bytes (the kernels address through 32-bit buffer descriptors)."""
+        oh, ow = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1          # stem output
+        ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1                # after the max pool
+        per_image = 2 * max(oh * ow * 64, ph * pw * 64 * self.expansion, ((H + 1) // 2) * ((W + 1) // 2) * 16)
+        return max(1, (2 ** 31 - 1) // per_image)
+
     def forward(self, x):
+        n = x.shape[0]
+        limit = self.max_batch(*(x.shape[1:3] if x.dtype == torch.uint8 else x.shape[2:4]))
+        if n > limit:       # transparently split what one engine call cannot address
+            parts = [self.forward(x[i:i + limit]) for i in range(0, n, limit)]
+            return torch.cat([p.reshape(-1, p.shape[-1]) for p in parts], dim=0)
         x, B, H, W, fmt, ws = self._prepare(x)
         D = self._head_in_dim() if self.without_fc else self.out_dim
         out = torch.empty(B, D, dtype=torch.float32, device=x.device)

@@ -144,3 +144,27 @@ def test_baseline_size_forward_properties():
     net.autotune = False
     dy = net(y).cpu()
     assert dy.shape == (2048,) and torch.isfinite(dy).all()
+
+
+def test_batches_beyond_the_32bit_descriptor_limit_are_split():
+    """An activation tensor of one engine call must stay below 2^31 bytes; the host object splits
+    larger batches and the result equals the per-chunk calls bit for bit."""
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet50', seed=7)
+    net = make_net('resnet50', {}, sd, 'bf16')
+    H = W = 1024
+    limit = net.max_batch(H, W)
+    assert limit == 63                       # layer1 maps: 256 x 256 x 256 x 2 B per image
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randint(0, 256, (limit + 3, H, W, 3), generator=g, dtype=torch.uint8, device='cuda')
+    full = net(x)
+    assert full.shape == (limit + 3, 2048)
+    assert torch.equal(full[:limit], net(x[:limit]))
+    assert torch.equal(full[limit:], net(x[limit:]))
+    from dirtorch_amd import _lib
+    with pytest.raises(_lib.DirError) as ei:      # the raw engine call refuses, loudly
+        ws = net._workspace(limit + 3, H, W)
+        out = torch.empty(limit + 3, 2048, device='cuda')
+        _lib.call('dir_forward', net._engine, _lib.ptr(x), limit + 3, H, W, _lib.DIR_IMG_U8_NHWC, _lib.ptr(out),
+                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    assert '2^31' in str(ei.value)
