@@ -277,6 +277,24 @@ int dir_conv_bn_act(const void* x, const void* w, const float* bias, const void*
     DIR_CATCH
 }
 
+int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, const void* res, void* y,
+                           int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                           int OH, int OW, int relu, int dtype, int variant, int ksplit, void* scratch,
+                           size_t scratch_bytes, int* ksplit_used, void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, x, w, bias, res, y, B, H, W, Cin, Cout, R, S, stride, pad, OH, OW, relu);
+    if (rc != DIR_OK) return rc;
+    if (variant < 0) variant = conv_pick_variant(a);
+    a.ksplit = ksplit < 0 ? conv_splitk_factor(variant, a) : ksplit;
+    a.partial = (float*)scratch;
+    if (a.ksplit > 1 && conv_splitk_bytes(a, a.ksplit) > scratch_bytes)
+        return fail(DIR_ERR_WORKSPACE, "conv: split-K scratch too small");
+    if (ksplit_used) *ksplit_used = a.ksplit > 1 ? a.ksplit : 1;
+    return conv_launch(a, dtype, variant, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res, void* y,
                           int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int OH, int OW, int relu, int dtype, void* stream) {

@@ -15,6 +15,11 @@ struct ConvArgs {
     int M;     // B*OH*OW
     int Ktot;  // R*S*Cin
     int T;     // Ktot / 64
+    // split-K (small M: too few output tiles to fill the chip).  ksplit > 1: workgroup (tile, z)
+    // accumulates K-steps [z*T'/ksplit, (z+1)*T'/ksplit) and stores raw fp32 sums to
+    // partial[z][M][Cout]; conv_splitk_finalize adds them in z order with bias / residual / ReLU.
+    int ksplit;      // 0 or 1 = off
+    float* partial;
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)
@@ -32,6 +37,7 @@ struct ConvVariant {
     ConvLaunchFn launch16[2];  // Cin == 16 stem instantiation, or nullptr
     int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip),
                                // 2 = persistent 256x256 1x1 (conv_persist.hip)
+    ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
 };
 
 bool conv1x1_persist_admissible(const ConvArgs& a);
@@ -44,6 +50,10 @@ const ConvVariant& conv_variant(int i);
 bool conv_variant_admissible(int v, const ConvArgs& a);
 int conv_pick_variant(const ConvArgs& a);
 int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream);
+// Split factor for variant `v` on problem `a` (1 = none) and the fp32 scratch it needs.
+int conv_splitk_factor(int v, const ConvArgs& a);
+size_t conv_splitk_bytes(const ConvArgs& a, int ksplit);
+constexpr size_t kSplitKMaxBytes = 64u << 20;   // scratch the engine reserves for the partial sums
 int conv_launch_naive(const ConvArgs& a, int dtype, hipStream_t stream);
 
 

@@ -29,6 +29,7 @@
 #include "conv_igemm.h"
 
 #include <string.h>
+#include <algorithm>
 
 namespace dir {
 
@@ -47,7 +48,9 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shr) {
     return mul ? (__umulhi(n, mul) >> shr) : n;  // mul == 0 encodes division by 1
 }
 
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16>
+// SPLITK instantiations (a few small-tile variants) carry the split-K bookkeeping; the others compile
+// exactly as if it did not exist - its extra scalar state costs 8-70 VGPRs in the big tiles.
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvArgs a) {
     static_assert(NST >= 2 && NST <= 4, "ring depth");
     static_assert((BK == 64 || BK == 32) && (!CIN16 || BK == 64), "K-step");
@@ -78,8 +81,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     const int lrow = lane & 31;
     const int lhi = lane >> 5;
 
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = wg % a.tiles_n;  // n fastest: blocks sharing an X tile run on one XCD
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int wg = SPLITK ? xcd_remap(blockIdx.x % ntiles, ntiles) : xcd_remap(blockIdx.x, gridDim.x);
+    const int kz = SPLITK ? blockIdx.x / ntiles : 0;  // split-K slice of this workgroup
+    const int tile_n = wg % a.tiles_n;   // n fastest: blocks sharing an X tile run on one XCD
     const int tile_m = wg / a.tiles_n;
 
     const __amdgpu_buffer_rsrc_t rsrc_x =
@@ -173,8 +178,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + tile_n * BN + wn * TN * 32 +
-                                                            i * 32 + 8 * g + 4 * lhi);
+            f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};   // split-K partial sums carry no bias
+            if (!SPLITK)
+                b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + tile_n * BN + wn * TN * 32 + i * 32 + 8 * g +
+                                                  4 * lhi);
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     const int n_glob = tile_n * BN + wn * TN * 32 + ecol;
     const int m_epi = tile_m * BM + wm * TM * 32;
     u32x4_t rres[PRE_RES ? TM : 1][PRE_RES ? NPASS : 1];
-    if (PRE_RES && a.res) {
+    if (PRE_RES && !SPLITK && a.res) {
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -224,8 +231,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     // Stages t+1 .. t+NST-1 stay in flight while stage t is consumed.  One barrier per K-step:
     // passing it means (a) stage t has landed for every wave (each waited on its own counted vmcnt
     // first), (b) every wave has finished reading slot (t-1) % NST, the slot refilled right after.
-    const int T = a.T;
     const int cpb = CIN16 ? 1 : (a.Cin / BK);  // K-steps per filter tap
+    const int t_begin = SPLITK ? (int)((long)a.T * kz / a.ksplit) : 0;
+    const int T = SPLITK ? (int)((long)a.T * (kz + 1) / a.ksplit) - t_begin : a.T;  // this workgroup's K-steps
     // K order: channel slice outermost, filter taps innermost.  Consecutive K-steps of a 3x3 conv
     // then read the SAME 64-channel slice of the input at pixel-shifted positions, so eight of the
     // nine tap reads hit the XCD's L2 (a tap-major order spaced those re-reads Cin/64 steps apart,
@@ -233,6 +241,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     // from the fabric - profiles/r01_bench_b32_hbm_pmc.json history).  The stem (CIN16) has one
     // K-step per filter row and keeps row order.
     int tap = 0, cc = 0, r = 0, s = 0;         // state of the step being ISSUED
+    if (SPLITK && t_begin > 0) {               // split-K: start in the middle of the K sequence
+        if (CIN16) {
+            r = tap = t_begin;
+        } else {
+            const int taps = a.R * a.S;
+            cc = t_begin / taps;
+            tap = t_begin - cc * taps;
+            r = tap / a.S;
+            s = tap - r * a.S;
+        }
+    }
     auto koff_now = [&]() {                    // bytes into the input, relative to tap (0,0)
         return CIN16 ? (r * a.W * 32) : (((r * a.W + s) * a.Cin + cc * BK) * 2);
     };
@@ -314,7 +333,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
             const f32x4_t f0 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4);
             const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
             const int m = m_epi + j * 32 + mrow;
-            if (m < a.M) {
+            if (SPLITK && m < a.M) {   // raw fp32 partial sums; conv_splitk_finalize does the rest
+                float* po = a.partial + ((size_t)kz * a.M + m) * a.Cout + n_glob;
+                *(DIR_GLOBAL f32x4_t*)po = f0;
+                *(DIR_GLOBAL f32x4_t*)(po + 4) = f1;
+            } else if (!SPLITK && m < a.M) {
                 float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
                 const size_t o = (size_t)m * a.Cout + n_glob;
                 if (a.res) {
@@ -359,7 +382,7 @@ static void fastdiv_init(uint32_t d, uint32_t& mul, uint32_t& shr) {
     shr = p - 32;
 }
 
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16>
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK = false>
 static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TN = BN / WGN / 32;
@@ -368,7 +391,7 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int EPI_BYTES = (NT / 64) * 32 * EROW;
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16>;
+    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -388,7 +411,8 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     // a short K loop never touches the far slots of the ring: ask for less LDS, more residency
     const int used = (b.T < NST ? b.T : NST) * STAGE_BYTES;
     const int lds = used > EPI_BYTES ? used : EPI_BYTES;
-    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(NT), lds, stream, b);
+    const int nz = SPLITK ? a.ksplit : 1;
+    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n * nz), dim3(NT), lds, stream, b);
     return hipGetLastError();
 }
 
@@ -396,24 +420,32 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
-     {nullptr, nullptr}, 0}
+     {nullptr, nullptr}, 0, {nullptr, nullptr}}
+// ... plus the split-K instantiation (small-M layers)
+#define DIR_VARIANT_SK(BM, BN, WGM, WGN, NST, BK, NAME)                                      \
+    {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
+     {nullptr, nullptr}, 0,                                                                  \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false, true>,                          \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false, true>}}
 // BN == 64 variants also carry the Cin == 16 (space-to-depth stem) instantiation.
 #define DIR_VARIANT16(BM, BN, WGM, WGN, NST, NAME)                                           \
     {NAME, BM, BN, 64 * WGM * WGN, NST, 64,                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, false>},                               \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, true>,                                 \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}, 0}
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}, 0, {nullptr, nullptr}}
 
 // name = <pixels>x<channels>_w<waves m>x<waves n>[_s<ring depth>][_k<K-step>]
 static const ConvVariant kVariants[] = {
-    DIR_VARIANT(128, 128, 2, 2, 2, 64, "128x128_w2x2"),
+    DIR_VARIANT_SK(128, 128, 2, 2, 2, 64, "128x128_w2x2"),
     DIR_VARIANT16(128, 64, 2, 2, 2, "128x64_w2x2"),
     DIR_VARIANT16(256, 64, 4, 1, 2, "256x64_w4x1"),
     DIR_VARIANT(256, 128, 4, 2, 2, 64, "256x128_w4x2"),
     DIR_VARIANT(128, 256, 2, 4, 2, 64, "128x256_w2x4"),
     DIR_VARIANT(256, 256, 4, 2, 2, 64, "256x256_w4x2"),
-    DIR_VARIANT(64, 128, 2, 2, 2, 64, "64x128_w2x2"),
+    DIR_VARIANT_SK(64, 128, 2, 2, 2, 64, "64x128_w2x2"),
     DIR_VARIANT16(64, 64, 2, 1, 2, "64x64_w2x1"),
     DIR_VARIANT(64, 128, 2, 2, 4, 64, "64x128_w2x2_s4"),
     DIR_VARIANT(128, 128, 2, 2, 3, 64, "128x128_w2x2_s3"),
@@ -435,10 +467,10 @@ static const ConvVariant kVariants[] = {
     // pipe - the 3x3 convs of layer3/4
     DIR_VARIANT(256, 256, 4, 4, 2, 64, "256x256_w4x4"),
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
-    {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
-    {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1},
+    {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
+    {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
-    {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2},
+    {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -454,6 +486,8 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
 }
+
+int conv_splitk_factor(int v, const ConvArgs& a);
 
 static int find_variant(const char* name) {
     for (int v = 0; v < kNumVariants; ++v)
@@ -476,29 +510,99 @@ int conv_pick_variant(const ConvArgs& a) {
         if (kVariants[v].kind == 1 && a.Cin == 64 && conv_variant_admissible(v, a)) return v;
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };
-    Cand c[5];
+    Cand c[8];
     int n = 0;
     if (T <= 1 || a.Cout % 128 != 0) {
         c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     } else if (a.Cout % 256 == 0 && T >= 6) {
         // 3x3: 16 waves of 64x64; 1x1: the persistent kernel (falls through when not admissible)
         c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : "256x256_persist1x1", 1};
-        c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1}, c[n++] = {"64x128_w2x2", 1};
+        c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
+        // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
+        // loop; with fewer than ~100 tiles even that leaves CUs idle and split-K takes over
+        c[n++] = {"64x128_w2x2_s4", 1}, c[n++] = {"64x128_w2x2", 1};
     } else if (a.Cout % 256 == 0 && T >= 3) {
         c[n++] = {"128x256_w2x4_s3_k32", 2}, c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
-        c[n++] = {"64x128_w2x2", 1};
+        c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};   // short K: more, smaller tiles
     } else {
-        c[n++] = {"256x128_w4x2_s3_k32", 2}, c[n++] = {"128x128_w2x2", 1}, c[n++] = {"64x128_w2x2", 1};
+        c[n++] = {"256x128_w4x2_s3_k32", 2}, c[n++] = {"128x128_w2x2", 1};
+        c[n++] = {T >= 8 ? "64x128_w2x2_s4" : "64x128_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     }
-    int last = -1;
+    int last = -1, prev = -1;
     for (int i = 0; i < n; ++i) {
         const int v = find_variant(c[i].name);
         if (v < 0 || !conv_variant_admissible(v, a)) continue;
+        prev = last;
         last = v;
         const long tiles = (long)ceil_div(a.M, kVariants[v].BM) * (a.Cout / kVariants[v].BN);
         if (tiles >= 192L * c[i].wg_per_cu) return v;
     }
+    // nothing fills the chip: the smallest tile, unless it is the split-K fallback of a list whose
+    // deep-ring sibling still gets ~100 workgroups
+    if (prev >= 0 && last >= 0 && kVariants[last].launch_sk[0] != nullptr &&
+        strcmp(kVariants[prev].name, "64x128_w2x2_s4") == 0 &&
+        (long)ceil_div(a.M, 64) * (a.Cout / 128) >= 96)
+        return prev;
     return last;
+}
+
+// ---- split-K ---------------------------------------------------------------------------------------
+// y = act(sum_z partial[z] + bias (+ res)): the z order is fixed, so the result does not depend on
+// which workgroup finished first.  8 channels per lane.
+template <class DT>
+__global__ void conv_splitk_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                            const uint16_t* __restrict__ res, uint16_t* __restrict__ y,
+                                            long total8, int Cout, long MC, int ksplit, int relu) {
+    const long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i8 >= total8) return;
+    const long o = i8 * 8;
+    const int n = (int)(o % Cout);
+    float v[8];
+    const f32x4_t b0 = *(const DIR_GLOBAL f32x4_t*)(bias + n), b1 = *(const DIR_GLOBAL f32x4_t*)(bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = b0[e], v[4 + e] = b1[e];
+    for (int z = 0; z < ksplit; ++z) {
+        const float* p = partial + (size_t)z * MC + o;
+        const f32x4_t p0 = *(const DIR_GLOBAL f32x4_t*)p, p1 = *(const DIR_GLOBAL f32x4_t*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p0[e], v[4 + e] += p1[e];
+    }
+    if (res) {
+        const u32x4_t rv = gload16(res + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo, hi;
+            DT::unpack(rv[e], lo, hi);
+            v[2 * e] += lo;
+            v[2 * e + 1] += hi;
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    u32x4_t ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
+    gstore16(y + o, ov);
+}
+
+size_t conv_splitk_bytes(const ConvArgs& a, int ksplit) {
+    return ksplit > 1 ? (size_t)ksplit * a.M * a.Cout * sizeof(float) : 0;
+}
+
+// When a layer has too few output tiles to give every CU work (batch 1 at the deep stages), the K loop
+// is cut into slices that run as separate workgroups.  Only the implicit-GEMM variants split, only
+// when each slice keeps >= 4 K-steps, and only within the scratch the engine reserves.
+int conv_splitk_factor(int v, const ConvArgs& a) {
+    if (v < 0 || v >= kNumVariants || kVariants[v].launch_sk[0] == nullptr || a.Cin == 16) return 1;
+    const ConvVariant& cv = kVariants[v];
+    const long tiles = (long)ceil_div(a.M, cv.BM) * (a.Cout / cv.BN);
+    const int T = a.Ktot / cv.BK;
+    if (tiles > 160 || T < 8) return 1;
+    int s = (int)std::min<long>(std::min<long>(8, 512 / tiles), T / 4);
+    while (s > 1 && conv_splitk_bytes(a, s) > kSplitKMaxBytes) --s;
+    return s < 2 ? 1 : s;
 }
 
 int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
@@ -522,11 +626,31 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (!conv_variant_admissible(variant, a))
         return fail(DIR_ERR_INVALID, "conv: variant not admissible for this shape");
     const ConvVariant& cv = kVariants[variant];
+    if (a.ksplit > 1) {
+        if (cv.launch_sk[0] == nullptr || cin16)
+            return fail(DIR_ERR_INVALID, "conv: this variant has no split-K form");
+        if (!a.partial || ((uintptr_t)a.partial & 15))
+            return fail(DIR_ERR_INVALID, "conv: split-K needs a 16-byte aligned fp32 scratch buffer");
+        if (a.ksplit > a.Ktot / cv.BK) return fail(DIR_ERR_INVALID, "conv: more K slices than K-steps");
+    }
     hipError_t e = cv.kind == 1   ? conv_patch3x3_launch(a, dtype, stream)
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
+                   : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)
         return fail(DIR_ERR_HIP, std::string("conv launch ") + cv.name + ": " + hipGetErrorString(e));
+    if (a.ksplit > 1) {
+        const long MC = (long)a.M * a.Cout, total8 = MC / 8;
+        const dim3 grid((unsigned)((total8 + 255) / 256));
+        if (dtype == DIR_BF16)
+            hipLaunchKernelGGL(conv_splitk_finalize_kernel<BF16>, grid, dim3(256), 0, stream, a.partial, a.bias,
+                               a.res, a.y, total8, a.Cout, MC, a.ksplit, a.relu);
+        else
+            hipLaunchKernelGGL(conv_splitk_finalize_kernel<FP16>, grid, dim3(256), 0, stream, a.partial, a.bias,
+                               a.res, a.y, total8, a.Cout, MC, a.ksplit, a.relu);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv split-K finalize: ") + hipGetErrorString(e));
+    }
     return DIR_OK;
 }
 

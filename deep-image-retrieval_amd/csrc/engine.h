@@ -38,7 +38,7 @@ struct ProfSlot {
 };
 
 struct Plan {  // byte offsets into the caller's workspace for one (B, H, W)
-    size_t s2d, stem, bufA, bufB, t1, t2, ds, x4, pooled, fcout, total;
+    size_t s2d, stem, bufA, bufB, t1, t2, ds, x4, splitk, pooled, fcout, total;
     int H2, W2, OH1, OW1, PH, PW;
 };
 
@@ -75,6 +75,7 @@ struct dir_engine {
                 int* fh, int* fw, int* fc, void* ws, size_t ws_bytes, hipStream_t stream);
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
                  int H, int W, int OH, int OW, hipStream_t stream);
+    float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
                    hipStream_t stream);
     int prof_end(hipStream_t stream);

@@ -285,6 +285,7 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->t2 = take(t2 ? t2 : 256);
     p->ds = take(ds ? ds : 256);
     p->x4 = take(x4 ? x4 : 256);
+    p->splitk = take(kSplitKMaxBytes);   // fp32 partial sums of split-K convs (small-M layers)
     p->pooled = take((size_t)B * head_dim * 4);
     p->fcout = take((size_t)B * std::max(desc.out_dim, head_dim) * 4);
     p->total = off;
@@ -345,6 +346,7 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
         a.pad = L.pad;
     }
     a.relu = L.relu ? 1 : 0;
+    a.partial = splitk_scratch;
     a.M = B * OH * OW;
     a.Ktot = a.R * a.S * a.Cin;
     a.T = a.Ktot / 64;
@@ -363,6 +365,7 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
         float best = 1e30f;
         for (int v = 0; v < conv_variant_count(); ++v) {
             if (!conv_variant_admissible(v, a)) continue;
+            a.ksplit = conv_splitk_factor(v, a);
             int rc = conv_launch(a, dtype, v, stream);  // warm-up (also sets func attributes)
             if (rc != DIR_OK) return rc;
             float ms = 1e30f;
@@ -388,7 +391,9 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
         L.tuned[a.M] = variant;
     }
     if (variant < 0) variant = conv_pick_variant(a);
-    int rc = prof_begin(L.name, std::string("conv_igemm<") + conv_variant(variant).name + ">",
+    a.ksplit = conv_splitk_factor(variant, a);
+    int rc = prof_begin(L.name, std::string("conv_igemm<") + conv_variant(variant).name +
+                                    (a.ksplit > 1 ? "/k" + std::to_string(a.ksplit) : "") + ">",
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     rc = conv_launch(a, dtype, variant, stream);
@@ -418,6 +423,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     uint16_t* ds = (uint16_t*)(base + p.ds);
     float* pooled = (float*)(base + p.pooled);
     float* fcout = (float*)(base + p.fcout);
+    splitk_scratch = (float*)(base + p.splitk);
 
     // 1. image -> space-to-depth NHWC16
     if (img) {

@@ -64,6 +64,8 @@ SIGNATURES = {
     'dir_conv_variant_name': (c_int, [c_int, c_char_p, c_int]),
     'dir_conv_bn_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14
                         + [c_void_p]),
+    'dir_conv_bn_act_splitk': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 15 +
+                               [c_void_p, c_size_t, POINTER(c_int), c_void_p]),
     'dir_conv_bn_act_naive': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                               + [c_int] * 13 + [c_void_p]),
     'dir_prep_input': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p,

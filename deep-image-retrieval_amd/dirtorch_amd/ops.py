@@ -60,8 +60,10 @@ def pack_stem_weight(w_oihw, dtype=torch.bfloat16):
 
 
 def conv_bn_act(x, w, bias, res=None, stride=1, pad=0, relu=True, out_hw=None, variant=-1,
-                naive=False):
-    """x NHWC [B,H,W,Cin] 16-bit, w [Cout,R,S,Cin] 16-bit, bias fp32 [Cout] -> NHWC [B,OH,OW,Cout]."""
+                naive=False, ksplit=None):
+    """x NHWC [B,H,W,Cin] 16-bit, w [Cout,R,S,Cin] 16-bit, bias fp32 [Cout] -> NHWC [B,OH,OW,Cout].
+    ksplit: None = plain launch; n > 1 = split-K into n slices; -1 = the engine's own choice
+    (conv_bn_act.last_ksplit holds what was used)."""
     _need_cuda(x, w, bias, res)
     B, H, W, Cin = x.shape
     Cout, R, S, Cin2 = w.shape
@@ -75,7 +77,14 @@ def conv_bn_act(x, w, bias, res=None, stride=1, pad=0, relu=True, out_hw=None, v
     y = torch.empty(B, OH, OW, Cout, dtype=x.dtype, device=x.device)
     args = [ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), B, H, W, Cin, Cout, R, S, stride, pad, OH,
             OW, int(bool(relu)), _dtype_code(x)]
-    if naive:
+    if ksplit is not None:
+        n = 8 if ksplit < 0 else max(int(ksplit), 1)
+        scratch = torch.empty(n * B * OH * OW * Cout, dtype=torch.float32, device=x.device)
+        used = ctypes.c_int()
+        call('dir_conv_bn_act_splitk', *args, int(variant), int(ksplit), ptr(scratch), scratch.numel() * 4,
+             ctypes.byref(used), stream_ptr())
+        conv_bn_act.last_ksplit = used.value
+    elif naive:
         call('dir_conv_bn_act_naive', *args, stream_ptr())
     else:
         call('dir_conv_bn_act', *args, int(variant), stream_ptr())

@@ -147,6 +147,15 @@ int dir_conv_variant_name(int variant, char* buf, int cap);
 int dir_conv_bn_act(const void* x, const void* w, const float* bias, const void* res, void* y,
                     int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
                     int pad, int OH, int OW, int relu, int dtype, int variant, void* stream);
+/* Same convolution with the K loop cut into `ksplit` slices that run as separate workgroups and meet in
+ * an fp32 scratch buffer (ksplit * B*OH*OW * Cout floats; slices are added in a fixed order, then bias /
+ * residual / ReLU) - what the engine does for layers with too few output tiles to fill 256 CUs (batch 1
+ * at the deep stages).  ksplit < 0: the engine's own choice for that variant (reported in *ksplit_used);
+ * variants without a split-K form accept only ksplit <= 1. */
+int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, const void* res, void* y,
+                           int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                           int OH, int OW, int relu, int dtype, int variant, int ksplit, void* scratch,
+                           size_t scratch_bytes, int* ksplit_used, void* stream);
 /* Slow, obviously-correct direct convolution with the same contract (device-side checker). */
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res,
                           void* y, int B, int H, int W, int Cin, int Cout, int R, int S,

@@ -119,6 +119,58 @@ def test_conv_variant_vs_oracle(shape, variant, dname):
     check_close(y, ref, dname, '%s variant %s %s' % (name, names[variant], dname))
 
 
+# (name, B, H, W, Cin, Cout, k, stride, pad, residual, relu): K loops long enough to cut
+SPLITK_SHAPES = [
+    ('3x3_c256', 1, 12, 9, 256, 256, 3, 1, 1, False, True),        # 36 K-steps, taps x channel slices
+    ('3x3_s2_res', 2, 15, 14, 128, 128, 3, 2, 1, True, True),      # 18 K-steps, stride 2, residual
+    ('1x1_k1024', 1, 10, 13, 1024, 256, 1, 1, 0, False, True),     # 16 K-steps
+    ('1x1_k512_res_norelu', 3, 7, 5, 512, 128, 1, 1, 0, True, False),
+]
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('ksplit', [2, 3, 4, 8, -1])
+@pytest.mark.parametrize('vname', ['128x128_w2x2', '64x128_w2x2'])
+@pytest.mark.parametrize('shape', SPLITK_SHAPES, ids=[s[0] for s in SPLITK_SHAPES])
+def test_conv_splitk_vs_oracle(shape, vname, ksplit, dname):
+    """Split-K (K loop cut across workgroups, fp32 partial sums added in slice order) against the
+    fp32 oracle, and against the unsplit launch: same products, one more fp32 association."""
+    ops = _ops()
+    name, B, H, W, Cin, Cout, k, stride, pad, use_res, relu = shape
+    variant = ops.conv_variant_names().index(vname)
+    dt = DTYPES[dname]
+    x = _rand((B, H, W, Cin), 1).to(dt)
+    w = _rand((Cout, k, k, Cin), 2, (2.0 / (k * k * Cin)) ** 0.5).to(dt)
+    bias = _rand((Cout,), 3, 0.2)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _rand((B, OH, OW, Cout), 4).to(dt) if use_res else None
+    ref = conv_reference(x, w, bias, res, stride, pad, relu)
+    args = (x.cuda(), w.cuda(), bias.cuda(), None if res is None else res.cuda())
+    kw = dict(stride=stride, pad=pad, relu=relu, variant=variant)
+    y = ops.conv_bn_act(*args, ksplit=ksplit, **kw)
+    used = ops.conv_bn_act.last_ksplit
+    assert used == (ksplit if ksplit > 0 else used) and used >= 2      # these shapes all split when asked to choose
+    check_close(y, ref, dname, '%s %s split-K %d %s' % (name, vname, used, dname))
+    plain = ops.conv_bn_act(*args, **kw)
+    # vs the unsplit kernel: at most a 1-ulp flip of the 16-bit output where the fp32 sums differ
+    diff = (y.float() - plain.float()).abs()
+    assert float(diff.max()) <= 2 * RTOL[dname] * float(plain.float().abs().max())
+    assert float((diff > 0).float().mean()) < 0.05
+
+
+def test_conv_splitk_argument_errors():
+    ops = _ops()
+    from dirtorch_amd import _lib
+    x = _rand((1, 8, 8, 256), 1).to(torch.bfloat16).cuda()
+    w = _rand((256, 1, 1, 256), 2, 0.05).to(torch.bfloat16).cuda()
+    b = torch.zeros(256, device='cuda')
+    names = ops.conv_variant_names()
+    with pytest.raises(_lib.DirError):      # no split-K form for this variant
+        ops.conv_bn_act(x, w, b, variant=names.index('256x256_w4x2'), ksplit=2)
+    with pytest.raises(_lib.DirError):      # more slices than K-steps
+        ops.conv_bn_act(x, w, b, variant=names.index('128x128_w2x2'), ksplit=5)
+
+
 @pytest.mark.parametrize('dname', ['bf16', 'fp16'])
 def test_naive_conv_vs_oracle(dname):
     ops = _ops()
