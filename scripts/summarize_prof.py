@@ -20,12 +20,13 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)>', name)
-    if m:   # <DT, BM, BN, WGM, WGN, NST, BK, CIN16> -> the variant names of csrc/conv_igemm.hip
-        dt, bm, bn, wm, wn, nst, bk, c16 = m.groups()
-        return 'conv_igemm<%sx%s_w%sx%s%s%s>%s[%s]' % (bm, bn, wm, wn, '_s' + nst if nst != '2' else '',
-                                                      '_k' + bk if bk != '64' else '',
-                                                      '/stem' if c16 == 'true' else '', dt.lower())
+    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>', name)
+    if m:   # <DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK> -> the variant names of csrc/conv_igemm.hip
+        dt, bm, bn, wm, wn, nst, bk, c16, sk = m.groups()
+        return 'conv_igemm<%sx%s_w%sx%s%s%s%s>%s[%s]' % (bm, bn, wm, wn, '_s' + nst if nst != '2' else '',
+                                                        '_k' + bk if bk != '64' else '',
+                                                        '/splitk' if sk == 'true' else '',
+                                                        '/stem' if c16 == 'true' else '', dt.lower())
     m = re.search(r'conv1x1_persist_kernel<dir::(\w+)>', name)
     if m:
         return 'conv_igemm<256x256_persist1x1>[%s]' % m.group(1).lower()
