@@ -406,6 +406,11 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
                         void* feat_out, int* fh, int* fw, int* fc, void* ws, size_t ws_bytes,
                         hipStream_t stream) {
     if (!finalized) return fail(DIR_ERR_STATE, "forward before finalize");
+    int cur_dev = -1;
+    DIR_HIP_CHECK(hipGetDevice(&cur_dev));
+    if (cur_dev != device)   // the weights live on `device`; launching elsewhere would fault
+        return fail(DIR_ERR_STATE, "forward: the current HIP device (" + std::to_string(cur_dev) +
+                                       ") is not the engine's device (" + std::to_string(device) + ")");
     Plan p;
     int rc = plan(B, H, W, &p);
     if (rc != DIR_OK) return rc;

@@ -167,38 +167,49 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const float* __restr
                                                            const float* __restrict__ qsub,
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ alpha) {
+    // two P rows per wave: every Q row fetched from L2 feeds two dot products
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= NP) return;
-    f32x4_t pv[KV], sv[KV];
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (i0 >= NP) return;
+    const bool two = i0 + 1 < NP;
+    f32x4_t pa[KV], pb[KV], sv[KV];
 #pragma unroll
     for (int c = 0; c < KV; ++c) {
         const int k = (c * 64 + lane) * 4;
-        pv[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        sv[c] = pv[c];
+        pa[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        pb[c] = pa[c];
+        sv[c] = pa[c];
         if (k < K) {
-            pv[c] = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)i * ldp + k);
+            pa[c] = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)i0 * ldp + k);
+            if (two) pb[c] = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)(i0 + 1) * ldp + k);
             if (qsub) sv[c] = *(const DIR_GLOBAL f32x4_t*)(qsub + k);
         }
     }
-    const float al = alpha ? alpha[i] : 1.f;
-    const float bi = bias ? bias[i] : 0.f;
+    const float al0 = alpha ? alpha[i0] : 1.f, al1 = (alpha && two) ? alpha[i0 + 1] : 1.f;
+    const float bi0 = bias ? bias[i0] : 0.f, bi1 = (bias && two) ? bias[i0 + 1] : 0.f;
     for (int j = 0; j < NQ; ++j) {
-        float s = 0.f;
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int c = 0; c < KV; ++c) {
             const int k = (c * 64 + lane) * 4;
             if (k < K) {
                 const f32x4_t q = *(const DIR_GLOBAL f32x4_t*)(Q + (size_t)j * ldq + k) - sv[c];
-                s = fmaf(pv[c][0], q[0], s);
-                s = fmaf(pv[c][1], q[1], s);
-                s = fmaf(pv[c][2], q[2], s);
-                s = fmaf(pv[c][3], q[3], s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0 = fmaf(pa[c][e], q[e], s0);
+                    s1 = fmaf(pb[c][e], q[e], s1);
+                }
             }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) out[(size_t)j * ldo + i] = al * s + bi;
+        for (int off = 32; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off, 64);
+            s1 += __shfl_xor(s1, off, 64);
+        }
+        if (lane == 0) {
+            out[(size_t)j * ldo + i0] = al0 * s0 + bi0;
+            if (two) out[(size_t)j * ldo + i0 + 1] = al1 * s1 + bi1;
+        }
     }
 }
 
@@ -208,7 +219,7 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
     if (NP <= 0 || NQ <= 0) return DIR_OK;
     if (NQ <= 32 && K <= 2048 && K > 0 && !(K & 3) && !(ldp & 3) && !(ldq & 3) &&
         !((uintptr_t)P & 15) && !((uintptr_t)Q & 15) && !(qsub && ((uintptr_t)qsub & 15))) {
-        const unsigned blocks = (unsigned)ceil_div(NP, 4);
+        const unsigned blocks = (unsigned)ceil_div(NP, 8);   // 4 waves x 2 rows
         if (K <= 1024)
             hipLaunchKernelGGL(gemm_nt_small_kernel<4>, dim3(blocks), dim3(256), 0, stream, P, ldp,
                                Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha);

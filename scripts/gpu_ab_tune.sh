@@ -6,8 +6,8 @@ pick='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_p
 cp profiles/r01_tuned_variants_b32_1024.txt /tmp/old_tune.txt
 rm -f /tmp/new_tune.txt
 for i in 1 2 3; do
-  echo -n "old "; DIRTORCH_AMD_TUNE_CACHE=/tmp/old_tune.txt timeout 600 python bench.py --cpu-seconds 0 2>/dev/null | tail -1 | python -c "$pick"
-  echo -n "new "; DIRTORCH_AMD_TUNE_CACHE=/tmp/new_tune.txt timeout 600 python bench.py --cpu-seconds 0 2>/dev/null | tail -1 | python -c "$pick"
+  echo -n "old "; DIRTORCH_AMD_TUNE_CACHE=/tmp/old_tune.txt timeout 600 python bench.py --cpu-seconds 0 --autotune 2>/dev/null | tail -1 | python -c "$pick"
+  echo -n "new "; DIRTORCH_AMD_TUNE_CACHE=/tmp/new_tune.txt timeout 600 python bench.py --cpu-seconds 0 --autotune 2>/dev/null | tail -1 | python -c "$pick"
 done
 cp /tmp/new_tune.txt gpurun_out/tune_b32_v4.txt
 awk '{print $3}' gpurun_out/tune_b32_v4.txt | sort | uniq -c | sort -rn | head -8

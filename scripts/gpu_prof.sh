@@ -4,7 +4,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export DIRTORCH_AMD_TUNE_CACHE=$R/gpurun_out/tune_b32.txt
+# default bench command: tiles from the built-in heuristic (no autotune, no tuning cache)
+unset DIRTORCH_AMD_TUNE_CACHE
 ARGS="--steps 10 --warmup 2 --cpu-seconds 0"
 (cd $R && timeout 300 python bench.py $ARGS > gpurun_out/prof_bench_plain.json 2> gpurun_out/prof_bench_plain.err)
 (cd $R && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o bench -- python bench.py $ARGS > gpurun_out/prof_bench_traced.json 2> gpurun_out/prof_stats.err)
