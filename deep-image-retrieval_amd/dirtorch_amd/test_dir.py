@@ -58,6 +58,9 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
     loader = get_loader(dataset, trf_chain=transforms, preprocess=net.preprocess, iscuda=iscuda,
                         output=['img'], batch_size=bs, threads=threads, shuffle=False)
     net.eval()
+    if (not same_size and not ret_imgs and not flip and batch_size > 1 and net.iscuda
+            and os.environ.get('DIRTORCH_AMD_BUCKET_BATCH', '1') != '0'):
+        return _extract_bucketed(loader, len(dataset), net, batch_size, desc)
     feats, kept = [], []
     nbatches = (len(dataset) + bs - 1) // bs
     with torch.no_grad():
@@ -76,6 +79,46 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
     if not ret_imgs:
         return feats
     return (torch.cat(kept, dim=0) if same_size else kept), feats
+
+
+def _extract_bucketed(loader, n, net, batch_size, desc):
+    """Variable-size images, batched anyway: the loader still yields one image at a time (in order),
+    images are parked on the GPU in per-size buckets, a bucket runs as one batch when it holds
+    `batch_size` images (or at the end), and every descriptor lands at its image's index.  The
+    reference runs these datasets at batch 1 (test_dir.py:52-55); on the MI355X a batch of 8 same-size
+    1024^2 images runs 2.3x faster per image than batch 1.  DIRTORCH_AMD_BUCKET_BATCH=0 disables."""
+    out = None
+    buckets = {}                                   # (H, W, dtype) -> ([indices], [image tensors])
+    pending, cap = 0, 8 * batch_size               # bound the parked images
+
+    def run(key):
+        nonlocal out, pending
+        idx, imgs = buckets.pop(key)
+        d = net(torch.cat(imgs, dim=0))
+        d = d.reshape(len(idx), -1)
+        if out is None:
+            out = torch.empty(n, d.shape[1], dtype=d.dtype, device=d.device)
+        out[torch.tensor(idx, device=d.device)] = d
+        pending -= len(idx)
+
+    with torch.no_grad():
+        for i, (img,) in enumerate(tqdm.tqdm(loader, desc, total=n)):
+            img = common.variables([img], net.iscuda)[0]
+            key = (tuple(img.shape[1:]), img.dtype)
+            idx, imgs = buckets.setdefault(key, ([], []))
+            idx.append(i)
+            imgs.append(img)
+            pending += 1
+            if len(idx) == batch_size:
+                run(key)
+            elif pending >= cap:                   # many rare sizes: flush the fullest bucket
+                run(max(buckets, key=lambda k: len(buckets[k][0])))
+        for key in list(buckets):
+            run(key)
+    if out is None:                                # empty dataset / shard
+        D = net._head_in_dim() if net.without_fc else net.out_dim
+        out = torch.empty(0, D, dtype=torch.float32, device='cuda')
+    return out
 
 
 def extract_multiscale_features(dataset, scales, net, desc="Extract feats...", iscuda=True, threads=8):

@@ -233,3 +233,33 @@ def test_multiscale_device_resize_equals_cpu_pil_path(tmp_path, monkeypatch):
         ref = torch.nn.functional.normalize(O.pool(per_scale, pooling, 3), dim=1).numpy()
         err = 1 - O.cosine(outs[pooling, '1'], ref)
         assert np.all(err < tol), (pooling, err)
+
+
+def test_bucketed_batching_keeps_order_and_values(tmp_path, monkeypatch):
+    """Variable-size images batched by size on the GPU (test_dir._extract_bucketed) against the
+    reference's batch-1 loop: same rows in the same order; values equal up to the split-K
+    re-association that batch 1 triggers in the deep layers."""
+    import dir_oracle as O
+    from dirtorch_amd import datasets, nets
+    from dirtorch_amd import test_dir as td
+    sizes = [(96, 128), (130, 90), (96, 128), (64, 64), (96, 128), (130, 90), (96, 128), (80, 144), (96, 128),
+             (64, 64), (130, 90)]
+    names = ['im%02d.png' % i for i in range(len(sizes))]
+    save_images(str(tmp_path / 'imgs'), names, sizes, 5)
+    (tmp_path / 'list.txt').write_text('\n'.join(names) + '\n')
+    db = datasets.create('ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'))
+    net = nets.create_model('resnet18_rmac', pretrained='')
+    net.load_state_dict(O.synth_state_dict('resnet18', seed=7, gemp=3.0))
+    net.compute_dtype = 'fp16'
+    net.cuda().eval()
+    monkeypatch.setenv('DIRTORCH_AMD_BUCKET_BATCH', '1')
+    a = td.extract_image_features(db, '', net, threads=0, batch_size=3).cpu()
+    monkeypatch.setenv('DIRTORCH_AMD_BUCKET_BATCH', '0')
+    b = td.extract_image_features(db, '', net, threads=0, batch_size=3).cpu()
+    assert a.shape == b.shape == (len(sizes), 2048)
+    assert float((1 - (a * b).sum(1)).max()) < 1e-6
+    # identical images (none here) aside, rows must not be permuted: every row is closest to itself
+    assert torch.equal((a @ b.t()).argmax(1), torch.arange(len(sizes)))
+    ref = oracle_descriptors(O.synth_state_dict('resnet18', seed=7, gemp=3.0), 'resnet18',
+                             [str(tmp_path / 'imgs' / n) for n in names])
+    assert float((1 - (a * ref).sum(1)).max()) < 1e-4
