@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
     constexpr int QP = (TH + 3) * QW;        // 385 patch pixels
     constexpr int PLANE = 512 * 16;          // one channel-half plane, padded to 2 DMA instructions
     constexpr int WOFF = 2 * PLANE;          // filter after the patch: 4 x [64][64] swizzled slices
-    constexpr int TILE = TH * TW * 128;      // conv outputs kept for pooling (aliases patch + filter)
+    static_assert(TH * TW * 128 <= 2 * PLANE + 4 * 8192, "the conv-output tile aliases patch + filter");
     typedef typename DT::frag_t frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
