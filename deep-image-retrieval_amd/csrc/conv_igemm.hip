@@ -468,7 +468,7 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT(256, 256, 4, 4, 2, 64, "256x256_w4x4"),
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
-    {"256x128_patch3x3", 256, 128, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
+    {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}},
 };

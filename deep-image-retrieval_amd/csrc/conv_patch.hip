@@ -24,24 +24,27 @@ __device__ __forceinline__ void dma16p(__amdgpu_buffer_rsrc_t rsrc, char* lds, u
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <class DT, int CIN, int COUT>
-__global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
+// NTH = 256: four waves, each two output rows x all of Cout.  NTH = 512 (the 128-channel layers):
+// eight waves, the second four take the upper half of Cout - same LDS image, two waves per SIMD.
+template <class DT, int CIN, int COUT, int NTH>
+__global__ void __launch_bounds__(NTH) conv_patch3x3_kernel(const ConvArgs a) {
     constexpr int TH = 8, TW = 32;           // output tile
     constexpr int PH = TH + 2, PW = TW + 2;  // input patch
     constexpr int PP = PH * PW;              // 340 patch pixels
     constexpr int KC = CIN / 64;             // 64-channel planes
-    constexpr int NPL = (PP * 8 + 255) / 256;          // DMA instructions per lane per plane (11)
-    constexpr int PLANE_BYTES = NPL * 256 * 16;        // 45056: whole DMA instructions land inside
-    constexpr int TN = COUT / 32;            // channel tiles per wave (all of Cout)
+    constexpr int WGN = NTH / 256;           // wave groups along Cout
+    constexpr int NPL = (PP * 8 + NTH - 1) / NTH;      // DMA instructions per lane per plane (11 / 6)
+    constexpr int PLANE_BYTES = NPL * NTH * 16;        // whole DMA instructions land inside
+    constexpr int TN = COUT / 32 / WGN;      // channel tiles per wave
     constexpr int TMR = TH / 4;              // output rows per wave (one 32-pixel MFMA tile each)
     constexpr int NSTW = 3;                  // weight ring depth
     constexpr int WSTAGE = COUT * 128;       // one tap's [Cout][64] slice
-    constexpr int NBW = COUT * 8 / 256;      // weight DMA instructions per lane per stage
+    constexpr int NBW = COUT * 8 / NTH;      // weight DMA instructions per lane per stage
     constexpr int T = 9 * KC;
     constexpr int WOFF = KC * PLANE_BYTES;   // ring starts after the patch
     constexpr int EROW = TN * 128 + 16;
     typedef typename DT::frag_t frag_t;
-    static_assert(CIN % 64 == 0 && COUT % 32 == 0, "shape");
+    static_assert(CIN % 64 == 0 && COUT % (32 * WGN) == 0 && (NTH == 256 || NTH == 512), "shape");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -50,6 +53,8 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31;
     const int lhi = lane >> 5;
+    const int wrow = wave & 3;   // which pair of output rows
+    const int wn = wave >> 2;    // which slice of Cout
 
     // tile coordinates: blockIdx.x -> (b, tile_y, tile_x), x fastest
     const int tiles_x = (a.OW + TW - 1) / TW;
@@ -69,7 +74,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
     // ---- patch: PP pixels x KC planes, loaded once -----------------------------------------------
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        const int P = i * 256 + tid;   // chunk slot in the plane image
+        const int P = i * NTH + tid;   // chunk slot in the plane image
         const int p = P >> 3;          // patch pixel
         const int slot = P & 7;
         const int py = p / PW, px = p - py * PW;
@@ -80,7 +85,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
                               : kOOBp;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
-            dma16p(rsrc_x, smem + kc * PLANE_BYTES + (i * 256 + wave * 64) * 16, v, kc * 128);
+            dma16p(rsrc_x, smem + kc * PLANE_BYTES + (i * NTH + wave * 64) * 16, v, kc * 128);
     }
 
     // ---- weights: one [Cout][64] slice per K-step through an NSTW-slot ring ----------------------
@@ -88,11 +93,11 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
     uint32_t wvoff[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i)
-        wvoff[i] = (uint32_t)(((i * 32 + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
+        wvoff[i] = (uint32_t)(((i * (NTH / 8) + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
     auto issue_w = [&](int t, int slot) {
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
-            dma16p(rsrc_w, smem + WOFF + slot * WSTAGE + (i * 256 + wave * 64) * 16, wvoff[i], t * 128);
+            dma16p(rsrc_w, smem + WOFF + slot * WSTAGE + (i * NTH + wave * 64) * 16, wvoff[i], t * 128);
     };
 
     // ---- accumulators start at the bias ------------------------------------------------------------
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + i * 32 + 8 * g + 4 * lhi);
+            const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + (wn * TN + i) * 32 + 8 * g + 4 * lhi);
 #pragma unroll
             for (int j = 0; j < TMR; ++j)
 #pragma unroll
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
         frag_t xf[TMR][4];
 #pragma unroll
         for (int j = 0; j < TMR; ++j) {
-            const int p = (wave * TMR + j + r) * PW + s + lrow;  // patch pixel read by this lane
+            const int p = (wrow * TMR + j + r) * PW + s + lrow;  // patch pixel read by this lane
             const int swz = (p >> 1) & 7;
             const char* row = plane + p * 128;
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
         for (int ks = 0; ks < 4; ++ks) {
             frag_t wf[TN];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = *(const frag_t*)(wst + i * 4096 + woffk[ks]);
+            for (int i = 0; i < TN; ++i) wf[i] = *(const frag_t*)(wst + (wn * TN + i) * 4096 + woffk[ks]);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -172,6 +177,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
     constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
     const int ecol = (lane % LPR) * 8;
     const int erow = lane / LPR;
+    const int ncol = wn * TN * 32 + ecol;   // first of this lane's 8 output channels
 #pragma unroll
     for (int j = 0; j < TMR; ++j) {
 #pragma unroll
@@ -185,7 +191,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int oy = oy0 + wave * TMR + j;
+        const int oy = oy0 + wrow * TMR + j;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int mrow = pass * RPP + erow;
@@ -194,7 +200,7 @@ __global__ void __launch_bounds__(256) conv_patch3x3_kernel(const ConvArgs a) {
             const int ox = ox0 + mrow;
             if (oy < a.OH && ox < a.OW) {
                 float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-                const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * COUT + ecol;
+                const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * COUT + ncol;
                 if (a.res) {
                     const u32x4_t rv = gload16(a.res + o);
 #pragma unroll
@@ -226,16 +232,16 @@ bool conv_patch3x3_admissible(const ConvArgs& a) {
            a.Cin == a.Cout && (a.Cin == 64 || a.Cin == 128);
 }
 
-template <class DT, int C>
+template <class DT, int C, int NTH>
 static hipError_t launch_patch(const ConvArgs& a, hipStream_t stream) {
     constexpr int KC = C / 64;
-    constexpr int PLANE_BYTES = ((10 * 34 * 8 + 255) / 256) * 256 * 16;
-    constexpr int TN = C / 32;
+    constexpr int PLANE_BYTES = ((10 * 34 * 8 + NTH - 1) / NTH) * NTH * 16;
+    constexpr int TN = C / 32 / (NTH / 256);
     constexpr int MAIN = KC * PLANE_BYTES + 3 * C * 128;
-    constexpr int EPI = 4 * 32 * (TN * 128 + 16);
+    constexpr int EPI = (NTH / 64) * 32 * (TN * 128 + 16);
     constexpr int LDS = MAIN > EPI ? MAIN : EPI;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_patch3x3_kernel<DT, C, C>;
+    auto kern = conv_patch3x3_kernel<DT, C, C, NTH>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -247,14 +253,14 @@ static hipError_t launch_patch(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     const long blocks = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), LDS, stream, b);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTH), LDS, stream, b);
     return hipGetLastError();
 }
 
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
     if (a.Cin == 64)
-        return dtype == DIR_BF16 ? launch_patch<BF16, 64>(a, stream) : launch_patch<FP16, 64>(a, stream);
-    return dtype == DIR_BF16 ? launch_patch<BF16, 128>(a, stream) : launch_patch<FP16, 128>(a, stream);
+        return dtype == DIR_BF16 ? launch_patch<BF16, 64, 256>(a, stream) : launch_patch<FP16, 64, 256>(a, stream);
+    return dtype == DIR_BF16 ? launch_patch<BF16, 128, 512>(a, stream) : launch_patch<FP16, 128, 512>(a, stream);
 }
 
 }  // namespace dir

@@ -1,5 +1,6 @@
 #!/bin/bash
+# per-variant timing of single conv launches on the layer2-4 shapes (scripts/exp_conv_time.py)
 mkdir -p gpurun_out
-V="256x256_w4x2 256x256_w4x2_f1 256x256_w4x2_f1p 256x256_w4x2_p 256x256_w4x4 256x256_w4x4_f1p"
-python scripts/exp_conv_time.py $V 2>&1 | grep -v "amdgpu.ids\|^lib" | tee gpurun_out/exp_full.txt
-timeout 600 python -m pytest tests/test_ops_gpu.py -q -m gpu -x 2>&1 | tail -2
+V="${VARIANTS:-256x128_patch3x3 256x128_w4x2_s3_k32 128x128_w2x2 256x256_w4x4 128x256_w2x4_s3_k32}"
+python scripts/exp_conv_time.py $V 2>&1 | grep -v "amdgpu.ids\|^lib" | tee gpurun_out/exp_variants.txt
+timeout 600 python -m pytest tests/test_ops_gpu.py -q -m gpu -x -k "conv" 2>&1 | tail -2
