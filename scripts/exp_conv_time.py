@@ -24,12 +24,16 @@ for v in range(n):
     buf = ctypes.create_string_buffer(64)
     _lib.call('dir_conv_variant_name', v, buf, 64)
     names.append(buf.value.decode())
+ZEROS = os.environ.get('EXP_ZEROS') == '1'   # zero-filled operands: same instruction stream, far less switching power
 want = sys.argv[1:] or ['256x256_w4x2', '256x256_w4x4', '256x256_w4x2_s3_k32', '256x256_w4x2_s4_k32',
                         '256x256_persist1x1', '128x256_w2x4_s3_k32', '256x128_w4x2_s3_k32', '128x128_w2x2']
 print('lib', _lib.LIB_PATH)
 for sname, (B, H, W, Cin, Cout, k, st, pad, res) in SHAPES.items():
     x = (torch.randn(B, H, W, Cin, device='cuda') * 0.5).to(torch.bfloat16)
     w = (torch.randn(Cout, k, k, Cin, device='cuda') * 0.02).to(torch.bfloat16)
+    if ZEROS:
+        x.zero_()
+        w.zero_()
     bias = torch.zeros(Cout, device='cuda')
     OH = (H + 2 * pad - k) // st + 1
     r = (torch.randn(B, OH, OH, Cout, device='cuda')).to(torch.bfloat16) if res else None
