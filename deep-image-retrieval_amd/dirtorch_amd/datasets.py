@@ -3,6 +3,7 @@
 
     db = datasets.create('ROxford5K')                       # needs DB_ROOT
     db = datasets.create('ImageList("list.txt")')
+    db = datasets.create('ImageListLabels("list_with_labels.txt")')   # class-label AP / top-k
     db.get_image(i) -> PIL.Image ; db.get_key(i) ; len(db) ; db.get_query_db()
     db.eval_query_AP(q, scores) -> {'easy','medium','hard'} (revisited protocol) or a float
 
@@ -41,14 +42,56 @@ class Dataset(object):
             img = img.resize(resize, Image.LANCZOS if down else Image.BICUBIC)
         return img
 
+    def get_label(self, img_idx, toint=False):
+        raise NotImplementedError()
+
+    def has_label(self):
+        try:
+            self.get_label(0)
+            return True
+        except NotImplementedError:
+            return False
+
     def get_query_db(self):
         raise NotImplementedError()
 
+    # ---- class-label ground truth (dataset.py:71-105): images of the query's class are relevant ---
+    labels = None
+    c_relevant_idx = None
+
+    def get_query_groundtruth(self, query_idx, what='AP'):
+        query_db = self.get_query_db()
+        assert self.nclass == query_db.nclass
+        if what == 'label':
+            return query_db.get_label(query_idx)
+        if what != 'AP':
+            raise ValueError("Unknown ground-truth type: %s" % what)
+        gt = -np.ones(self.nimg, dtype=np.int8)                              # negatives
+        gt[self.c_relevant_idx.get(query_db.get_label(query_idx), [])] = 1   # same class (maybe none)
+        if query_db is self:
+            gt[query_idx] = 0                                                # the query itself: ignored
+        return gt
+
     def eval_query_AP(self, query_idx, scores):
-        raise NotImplementedError()
+        """sklearn AP of `scores` against the class ground truth; -1 when the query has no relevant
+        image (the caller leaves such queries out of the mean)."""
+        if self.c_relevant_idx is None:
+            raise NotImplementedError()
+        from .utils.evaluation import compute_AP
+        gt = self.get_query_groundtruth(query_idx, 'AP')
+        assert gt.shape == scores.shape, "scores should have shape %s" % str(gt.shape)
+        keep = gt != 0
+        if not (gt[keep] > 0).any():
+            return -1
+        return compute_AP(gt[keep] > 0, scores[keep])
 
     def eval_query_top(self, query_idx, scores, k=(1, 5, 10, 20, 50, 100)):
-        raise NotImplementedError()   # no labels on the retrieval benchmarks (dataset.py:97)
+        """1.0 / 0.0 per k: is an image of the query's class among the k best-scored ones."""
+        if not self.labels:
+            raise NotImplementedError()   # no labels on the retrieval benchmarks (dataset.py:97)
+        q_label = self.get_query_groundtruth(query_idx, 'label')
+        correct = np.array([l == q_label for l in self.labels], dtype=bool)[np.argsort(-scores)]
+        return {k_: float(correct[:k_].any()) for k_ in k if k_ < len(correct)}
 
     def original(self):
         return self
@@ -96,17 +139,105 @@ class ImageListROIs(Dataset):
         return img
 
 
-def compute_average_precision(positive_ranks):
-    """Trapezoidal AP of the revisited Oxford/Paris protocol (utils/evaluation.py:46-82):
-    positive_ranks = sorted zero-based ranks of the positives among the non-junk images."""
-    n = len(positive_ranks)
-    if not n:
-        return 0.0
-    ap = 0.0
-    for i, rank in enumerate(positive_ranks):
-        left = 1.0 if not rank else i / rank
-        ap += (left + (i + 1) / (rank + 1)) / (2.0 * n)
-    return ap
+from .utils.evaluation import compute_average_precision  # noqa: E402,F401  (kept importable from here)
+
+
+def find_and_list_classes(labels, cls_idx=None):
+    """classes = [name of class 0, name of class 1, ...], cls_idx = {name: index}: classes are numbered
+    in order of first appearance, after the indices forced through `cls_idx` (generic_func.py:8-44)."""
+    assert not isinstance(labels, set), 'labels must be ordered'
+    cls_idx = dict(cls_idx) if cls_idx else {}
+    present = set(labels)
+    for label in cls_idx:
+        assert label in present, "error: missing forced label '%s'" % str(label)
+    free = (i for i in range(len(present)) if i not in set(cls_idx.values()))
+    for label in labels:
+        if label not in cls_idx:
+            cls_idx[label] = next(free)
+    by_index = {i: c for c, i in cls_idx.items()}
+    assert sorted(by_index) == list(range(len(by_index))), 'class indices must be 0..n-1'
+    return [by_index[i] for i in range(len(by_index))], cls_idx
+
+
+def find_relevants(labels):
+    """{label: [indices of the images carrying it]} (generic_func.py:46-60)."""
+    assert not isinstance(labels, set), 'labels must be ordered'
+    rel = {}
+    for i, label in enumerate(labels):
+        rel.setdefault(label, []).append(i)
+    return rel
+
+
+class LabelledDataset(Dataset):
+    """Per-image class labels (generic.py:33-41)."""
+
+    def find_classes(self, *arg, **cls_idx):
+        labels = arg[0] if arg else self.labels
+        self.classes, self.cls_idx = find_and_list_classes(labels, cls_idx=cls_idx)
+        self.nclass = len(self.classes)
+        self.c_relevant_idx = find_relevants(self.labels)
+
+
+def _read_pairs(path):
+    rows = [e.strip().split(' ') for e in open(path) if e.strip()]
+    return [r[0] for r in rows], [r[1] for r in rows]
+
+
+class ImageListLabels(LabelledDataset):
+    """'<image path> <label>' per row of a .txt file, or a {path: label} .json; the images are their
+    own queries (generic.py:44-77)."""
+
+    def __init__(self, img_list_path, root=None):
+        self.root = root
+        if os.path.splitext(img_list_path)[1] == '.json':
+            import json
+            pairs = json.load(open(img_list_path))
+            self.imgs, self.labels = list(pairs.keys()), list(pairs.values())
+        else:
+            self.imgs, self.labels = _read_pairs(img_list_path)
+        self.find_classes()
+        self.nimg = len(self.imgs)
+        self.nquery = 0
+
+    def get_key(self, i):
+        return self.imgs[i]
+
+    def get_label(self, i, toint=False):
+        return self.cls_idx[self.labels[i]] if toint else self.labels[i]
+
+    def get_query_db(self):
+        return self
+
+
+class ImagesAndLabels(ImageListLabels):
+    """In-memory image and label lists sharing another dataset's class indices (generic.py:108-121)."""
+
+    def __init__(self, imgs, labels, cls_idx, root=None):
+        self.root, self.imgs, self.labels, self.cls_idx = root, imgs, labels, cls_idx
+        self.nclass = len(cls_idx)
+        self.nimg = len(imgs)
+        self.nquery = 0
+
+
+class ImageListLabelsQ(ImageListLabels):
+    """Database and query lists in two '<path> <label>' files (generic.py:80-105)."""
+
+    def __init__(self, img_list_path, query_list_path, root=None):
+        self.root = root
+        self.imgs, self.labels = _read_pairs(img_list_path)
+        self.qimgs, self.qlabels = _read_pairs(query_list_path)
+        self.find_classes()
+        self.nimg = len(self.imgs)
+        self.nquery = len(self.qimgs)
+
+    def find_classes(self, *arg, **cls_idx):
+        labels = arg[0] if arg else self.labels + self.qlabels
+        self.classes, self.cls_idx = find_and_list_classes(labels, cls_idx=cls_idx)
+        self.nclass = len(self.classes)
+        self.c_relevant_idx = find_relevants(self.labels)
+
+    def get_query_db(self):
+        return ImagesAndLabels(self.qimgs, self.qlabels, self.cls_idx, root=self.root)
 
 
 class ImageListRelevants(Dataset):
@@ -197,7 +328,8 @@ ROxford5K = _benchmark('ROxford5K', 'oxford5k', 'gnd_roxford5k.pkl')
 Paris6K = _benchmark('Paris6K', 'paris6k', 'gnd_paris6k.pkl')            # datasets/paris.py
 RParis6K = _benchmark('RParis6K', 'paris6k', 'gnd_rparis6k.pkl')
 
-_REGISTRY = {c.__name__: c for c in (ImageList, ImageListRelevants, Oxford5K, ROxford5K, Paris6K, RParis6K)}
+_REGISTRY = {c.__name__: c for c in (ImageList, ImageListLabels, ImageListLabelsQ, ImageListRelevants,
+                                     Oxford5K, ROxford5K, Paris6K, RParis6K)}
 
 
 def create(dataset_cmd):

@@ -31,3 +31,9 @@ def postproc_goldens():
 def head_goldens():
     import numpy as np
     return np.load(os.path.join(GOLDEN, 'head_goldens.npz'))
+
+
+@pytest.fixture(scope='session')
+def label_goldens():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, 'label_goldens.npz'))

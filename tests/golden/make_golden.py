@@ -2,7 +2,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py [model] [head] [postproc]
+    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py [model] [head] [postproc] [label]
 
 What is pinned (reference file:line):
     descriptors      dirtorch.nets.create_model(...)(x)      nets/__init__.py:24, rmac_resnet.py:39-69
@@ -13,6 +13,8 @@ What is pinned (reference file:line):
     matmul           dirtorch.utils.common.matmul            utils/common.py:30-38
     AP               compute_average_precision               utils/evaluation.py:46-82
     eval_query_AP    ImageListRelevants.eval_query_AP        datasets/generic.py:196-224
+    label AP / top-k Dataset.eval_query_AP / eval_query_top  datasets/dataset.py:71-105 (ImageListLabels[Q])
+    accuracy_topk, compute_average_precision_quantized       utils/evaluation.py:8-38,85-98
 
 Weights and images come from oracle/dir_oracle.py's deterministic generators (synth_state_dict,
 synth_images), so the fixtures hold only the reference's OUTPUTS (a few hundred KB).
@@ -104,6 +106,41 @@ def head_goldens():
     np.savez_compressed(os.path.join(HERE, 'head_goldens.npz'), **out)
 
 
+def label_goldens():
+    """Class-label evaluation (datasets/dataset.py:71-105, generic.py:44-121, utils/evaluation.py)."""
+    np.bool8 = np.bool_     # shim: dataset.py:99 uses an alias NumPy 2 removed
+    from dirtorch.datasets import generic as ref_generic
+    from dirtorch.utils import evaluation as ref_eval
+    r = np.random.RandomState(5)
+    labels = ['c%d' % r.randint(0, 6) for _ in range(40)]
+    qlabels = ['c%d' % r.randint(0, 7) for _ in range(9)]       # 'c6' has no database image
+    scores = r.standard_normal((40, 40)).astype(np.float32)
+    out = {'labels.db': np.array(labels), 'labels.q': np.array(qlabels), 'labels.scores': scores}
+    with tempfile.TemporaryDirectory() as d:
+        open(d + '/db.txt', 'w').write('\n'.join('im%02d.jpg %s' % (i, l) for i, l in enumerate(labels)) + '\n')
+        open(d + '/q.txt', 'w').write('\n'.join('q%02d.jpg %s' % (i, l) for i, l in enumerate(qlabels)) + '\n')
+        for tag, db in (('self', ref_generic.ImageListLabels(d + '/db.txt', root=d)),
+                        ('q', ref_generic.ImageListLabelsQ(d + '/db.txt', d + '/q.txt', root=d))):
+            nq = db.get_query_db().nimg
+            out['labels.%s.classes' % tag] = np.array(db.classes)
+            out['labels.%s.ap' % tag] = np.array([db.eval_query_AP(q, scores[q]) for q in range(nq)], dtype=np.float64)
+            tops = [db.eval_query_top(q, scores[q]) for q in range(nq)]
+            out['labels.%s.topk' % tag] = np.array([[t[k] for k in sorted(t)] for t in tops])
+            out['labels.%s.topk_keys' % tag] = np.array(sorted(tops[0]))
+    logits = r.standard_normal((12, 7)).astype(np.float32)
+    target = r.randint(0, 7, 12)
+    out['acc.logits'], out['acc.target'] = logits, target
+    out['acc.np'] = np.array(ref_eval.accuracy_topk(logits, target, topk=(1, 3, 5)), dtype=np.float64)
+    out['acc.torch'] = np.array([float(v) for v in ref_eval.accuracy_topk(
+        torch.from_numpy(logits), torch.from_numpy(target), topk=(1, 3, 5))])
+    rel = (r.uniform(size=50) < 0.2).astype(np.int64)
+    order = np.argsort(-r.standard_normal(50))
+    out['apq.labels'], out['apq.order'] = rel, order
+    out['apq.value'] = np.array(ref_eval.compute_average_precision_quantized(rel, order))
+    np.savez_compressed(os.path.join(HERE, 'label_goldens.npz'), **out)
+    print('label goldens written')
+
+
 def postproc_goldens():
     from sklearn.decomposition import PCA
     r = np.random.RandomState(3)
@@ -165,10 +202,12 @@ def postproc_goldens():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'head', 'postproc']
+    which = sys.argv[1:] or ['model', 'head', 'postproc', 'label']
     if 'model' in which:
         model_goldens()
     if 'head' in which:
         head_goldens()
     if 'postproc' in which:
         postproc_goldens()
+    if 'label' in which:
+        label_goldens()

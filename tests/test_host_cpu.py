@@ -192,3 +192,38 @@ def test_single_process_passthrough():
     assert dd.allgather_rows(x, 9) is x
     assert dd.rank() == 0 and dd.world_size() == 1
     assert torch.equal(dd.extract_sharded(_fake_extract, _FakeDB(9), '', _FakeNet()), x)
+
+
+def test_labelled_datasets_and_metrics_match_reference(label_goldens, tmp_path):
+    """ImageListLabels / ImageListLabelsQ class-label AP and top-k, accuracy_topk and the quantized
+    AP against outputs of the reference (tests/golden/label_goldens.npz)."""
+    import numpy as np
+    import torch
+    from dirtorch_amd import datasets
+    from dirtorch_amd.utils import evaluation
+    g = label_goldens
+    labels, qlabels, scores = list(g['labels.db']), list(g['labels.q']), g['labels.scores']
+    (tmp_path / 'db.txt').write_text('\n'.join('im%02d.jpg %s' % (i, l) for i, l in enumerate(labels)) + '\n')
+    (tmp_path / 'q.txt').write_text('\n'.join('q%02d.jpg %s' % (i, l) for i, l in enumerate(qlabels)) + '\n')
+    cases = (('self', datasets.create('ImageListLabels("%s", root="%s")' % (tmp_path / 'db.txt', tmp_path))),
+             ('q', datasets.create('ImageListLabelsQ("%s", "%s", root="%s")' % (tmp_path / 'db.txt', tmp_path / 'q.txt', tmp_path))))
+    for tag, db in cases:
+        assert db.has_label() and list(g['labels.%s.classes' % tag]) == db.classes
+        qdb = db.get_query_db()
+        assert (qdb is db) == (tag == 'self')
+        aps = np.array([db.eval_query_AP(q, scores[q]) for q in range(qdb.nimg)], dtype=np.float64)
+        np.testing.assert_allclose(aps, g['labels.%s.ap' % tag], rtol=0, atol=1e-12)
+        keys = list(g['labels.%s.topk_keys' % tag])
+        tops = [db.eval_query_top(q, scores[q]) for q in range(qdb.nimg)]
+        assert sorted(tops[0]) == keys
+        assert np.array_equal(np.array([[t[k] for k in keys] for t in tops]), g['labels.%s.topk' % tag])
+    assert -1 in g['labels.q.ap']                       # the query of a class without database images
+    with pytest.raises(NotImplementedError):            # unlabelled lists still have no AP
+        datasets.ImageList(imgs=['a.jpg']).eval_query_AP(0, np.zeros(1))
+    logits, target = g['acc.logits'], g['acc.target']
+    np.testing.assert_allclose(evaluation.accuracy_topk(logits, target, topk=(1, 3, 5)), g['acc.np'], atol=1e-12)
+    got = evaluation.accuracy_topk(torch.from_numpy(logits), torch.from_numpy(target), topk=(1, 3, 5))
+    np.testing.assert_allclose([float(v) for v in got], g['acc.torch'], atol=1e-7)
+    np.testing.assert_allclose(evaluation.compute_average_precision_quantized(g['apq.labels'], g['apq.order']),
+                               g['apq.value'], atol=1e-7)
+    assert evaluation.compute_average_precision_quantized(np.zeros(5, dtype=int), np.arange(5)) == 0
