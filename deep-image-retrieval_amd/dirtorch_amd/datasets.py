@@ -328,8 +328,40 @@ ROxford5K = _benchmark('ROxford5K', 'oxford5k', 'gnd_roxford5k.pkl')
 Paris6K = _benchmark('Paris6K', 'paris6k', 'gnd_paris6k.pkl')            # datasets/paris.py
 RParis6K = _benchmark('RParis6K', 'paris6k', 'gnd_rparis6k.pkl')
 
+
+
+def _listed(cls_name, base, sub, lst):
+    """A named list dataset under DB_ROOT/<sub>/ (datasets/landmarks.py, landmarks18.py)."""
+    def __init__(self):
+        root = os.path.join(_db_root(), sub)
+        base.__init__(self, os.path.join(root, lst), root + '/')
+    return type(cls_name, (base,), {'__init__': __init__})
+
+
+# name -> (labelled?, sub-directory, list file): extraction / whitening-set / distractor lists
+_LISTS = {
+    'Landmarks_clean': (True, 'landmarks', 'annotations/annotation_clean_train.txt'),
+    'Landmarks_clean_val': (True, 'landmarks', 'annotations/annotation_clean_val.txt'),
+    'Landmarks_lite': (True, 'landmarks', 'annotations/extra_landmark_images.txt'),
+    'Landmarks18_train': (True, 'landmarks18', 'lists/train.txt'),
+    'Landmarks18': (True, 'landmarks18', 'lists/train_all.txt'),
+    'Landmarks18_lite': (True, 'landmarks18', 'lists/train_lite.txt'),
+    'Landmarks18_mid': (True, 'landmarks18', 'lists/train_mid.txt'),
+    'Landmarks18_5K': (True, 'landmarks18', 'lists/train_5K.txt'),
+    'Landmarks18_val': (True, 'landmarks18', 'lists/val.txt'),
+    'Landmarks18_valdstr': (True, 'landmarks18', 'lists/val_distractors.txt'),
+    'Landmarks18_index': (False, 'landmarks18', 'lists/index.txt'),
+    'Landmarks18_new_index': (False, 'landmarks18', 'lists/index_new.txt'),
+    'Landmarks18_test': (False, 'landmarks18', 'lists/test.txt'),
+    'Landmarks18_pca': (False, 'landmarks18', 'lists/train_pca.txt'),
+    'Landmarks18_missing_index': (False, 'landmarks18', 'lists/missing_index.txt'),
+}
+_LISTED = {name: _listed(name, ImageListLabels if lab else ImageList, sub, lst)
+           for name, (lab, sub, lst) in _LISTS.items()}
+globals().update(_LISTED)
+
 _REGISTRY = {c.__name__: c for c in (ImageList, ImageListLabels, ImageListLabelsQ, ImageListRelevants,
-                                     Oxford5K, ROxford5K, Paris6K, RParis6K)}
+                                     Oxford5K, ROxford5K, Paris6K, RParis6K) + tuple(_LISTED.values())}
 
 
 def create(dataset_cmd):

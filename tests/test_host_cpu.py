@@ -61,7 +61,7 @@ def test_dataset_factory(tmp_path, monkeypatch):
     with pytest.raises(NotImplementedError):
         db.get_query_db()
     with pytest.raises(NameError):
-        datasets.create('Landmarks_clean')
+        datasets.create('Landmarks_dirty')
     with pytest.raises(SyntaxError):
         datasets.create('ImageList(__import__("os").getcwd())')     # literals only, no eval
     monkeypatch.delenv('DB_ROOT', raising=False)
@@ -227,3 +227,26 @@ def test_labelled_datasets_and_metrics_match_reference(label_goldens, tmp_path):
     np.testing.assert_allclose(evaluation.compute_average_precision_quantized(g['apq.labels'], g['apq.order']),
                                g['apq.value'], atol=1e-7)
     assert evaluation.compute_average_precision_quantized(np.zeros(5, dtype=int), np.arange(5)) == 0
+
+
+def test_named_list_datasets_resolve_under_db_root(tmp_path, monkeypatch):
+    """The Landmarks* names of datasets/landmarks.py and landmarks18.py: fixed list files under DB_ROOT."""
+    from dirtorch_amd import datasets
+    names = {'Landmarks_clean', 'Landmarks_clean_val', 'Landmarks_lite', 'Landmarks18_train', 'Landmarks18',
+             'Landmarks18_lite', 'Landmarks18_mid', 'Landmarks18_5K', 'Landmarks18_val', 'Landmarks18_valdstr',
+             'Landmarks18_index', 'Landmarks18_new_index', 'Landmarks18_test', 'Landmarks18_pca',
+             'Landmarks18_missing_index'}
+    assert names <= set(datasets._REGISTRY)
+    monkeypatch.setenv('DB_ROOT', str(tmp_path))
+    (tmp_path / 'landmarks18' / 'lists').mkdir(parents=True)
+    (tmp_path / 'landmarks18' / 'lists' / 'index.txt').write_text('a/1.jpg\nb/2.jpg\n')
+    (tmp_path / 'landmarks' / 'annotations').mkdir(parents=True)
+    (tmp_path / 'landmarks' / 'annotations' / 'annotation_clean_val.txt').write_text('x.jpg 7\ny.jpg 7\nz.jpg 9\n')
+    idx = datasets.create('Landmarks18_index')
+    assert len(idx) == 2 and idx.get_filename(1) == str(tmp_path / 'landmarks18') + '/b/2.jpg' and not idx.has_label()
+    val = datasets.create('Landmarks_clean_val')
+    assert len(val) == 3 and val.nclass == 2 and val.get_label(2) == '9' and val.get_label(2, toint=True) == 1
+    assert val.eval_query_AP(0, np.array([0.1, 0.9, 0.5], dtype=np.float32)) == 1.0
+    monkeypatch.delenv('DB_ROOT')
+    with pytest.raises(KeyError):
+        datasets.create('Landmarks18_pca')
