@@ -1,12 +1,9 @@
 #!/bin/bash
-# full GPU suite + smoke + benches (autotuned x2, default heuristic, batch 1/4)
+# what the driver runs at round end, plus the torchrun launch form: full GPU suite, smoke(), default bench
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/pytest18.log 2>&1
-echo "exit $?" >> gpurun_out/pytest18.log
-grep -v "Warning\|pin_memory\|^$" gpurun_out/pytest18.log | tail -4
+timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/pytest_final.log 2>&1
+echo "exit $?" >> gpurun_out/pytest_final.log
+grep -v "Warning\|pin_memory\|^$" gpurun_out/pytest_final.log | tail -4
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-pick='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["all_conv_mfma_frac"])'
-for i in 1 2; do timeout 600 python bench.py --cpu-seconds 0 --autotune 2>/dev/null | tail -1 | tee gpurun_out/bench18_$i.json | python -c "$pick"; done
-echo heuristic; timeout 600 python bench.py --cpu-seconds 0 2>/dev/null | tail -1 | python -c "$pick"
-echo b1; timeout 600 python bench.py --cpu-seconds 0 --batch 1 --steps 200 --warmup 20 --profile-every 1000 2>/dev/null | tail -1 | python -c "$pick"
-echo b4; timeout 600 python bench.py --cpu-seconds 0 --batch 4 --steps 100 --warmup 10 --profile-every 1000 2>/dev/null | tail -1 | python -c "$pick"
+timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -1 gpurun_out/bench_final.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 8 --warmup 2 --cpu-seconds 0 2>&1 | tail -1 | cut -c1-160
