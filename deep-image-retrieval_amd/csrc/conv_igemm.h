@@ -36,12 +36,15 @@ struct ConvVariant {
     ConvLaunchFn launch[2];    // [dtype]
     ConvLaunchFn launch16[2];  // Cin == 16 stem instantiation, or nullptr
     int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip),
-                               // 2 = persistent 256x256 1x1 (conv_persist.hip)
+                               // 2 = persistent 256x256 1x1 (conv_persist.hip),
+                               // 3 = register-stationary weights 1x1 (conv_wreg.hip)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
 };
 
 bool conv1x1_persist_admissible(const ConvArgs& a);
 hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+bool conv1x1_wreg_admissible(const ConvArgs& a);
+hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

@@ -471,6 +471,8 @@ static const ConvVariant kVariants[] = {
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}},
+    // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
+    {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -482,6 +484,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     const ConvVariant& cv = kVariants[v];
     if (cv.kind == 1) return a.Cout == cv.BN && conv_patch3x3_admissible(a);
     if (cv.kind == 2) return conv1x1_persist_admissible(a);
+    if (cv.kind == 3) return conv1x1_wreg_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
@@ -508,6 +511,12 @@ static int find_variant(const char* name) {
 int conv_pick_variant(const ConvArgs& a) {
     for (int v = 0; v < kNumVariants; ++v)
         if (kVariants[v].kind == 1 && a.Cin == 64 && conv_variant_admissible(v, a)) return v;
+    // the residual 1x1 convs with K <= 256 (layer2/3 conv3): weights stationary in registers, as long
+    // as every persistent workgroup gets at least ~4 pixel tiles to amortise loading them
+    {
+        const int v = find_variant("64x512_wreg1x1");
+        if (v >= 0 && conv_variant_admissible(v, a) && (long)ceil_div(a.M, 64) * (a.Cout / 512) >= 1024) return v;
+    }
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };
     Cand c[8];
@@ -635,6 +644,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     }
     hipError_t e = cv.kind == 1   ? conv_patch3x3_launch(a, dtype, stream)
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
+                   : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)

@@ -1,0 +1,248 @@
+// conv_wreg.hip — 1x1 convolution with the weights stationary in REGISTERS (gfx950).
+//
+// The residual 1x1 convs that close the layer2/layer3 bottlenecks (K = 128 / 256 -> 512 / 1024
+// channels, + residual + ReLU; dirtorch/nets/backbones/resnet.py:61-63,78-85) are bound by what a CU's
+// memory pipe can move (~35 GB/s per CU measured, LDS-DMA fills + residual loads + stores together),
+// and in the tiled kernels more than half of that is re-fetching the weight slice for every pixel
+// tile (profiles/: 805 MB of L2->LDS fill per launch for 603 MB of HBM bytes on layer3).  K is short
+// here, so a wave can simply KEEP its weights: 64 output channels x K = 256 inputs are 16 MFMA
+// A-fragments x 2 channel tiles = 128 VGPRs.  A persistent 8-wave workgroup owns 512 consecutive
+// output channels (64 per wave), loads them once, and then streams pixel tiles of 64: only the input
+// tile (32 KB for K = 256, double-buffered by LDS-DMA) is filled per step and it is shared by all
+// eight waves, so the input is re-read Cout/512 times instead of Cout/256 and the weights never.
+//
+// Everything else is the conv_igemm design: swapped MFMA roles (A = weights, B = pixels), XOR-swizzled
+// 128-byte LDS rows (swizzle applied to the DMA source chunk), LDS-staged fp32 epilogue with 16-byte
+// stores, K order = channel order.  The bias is added in the epilogue (the tiled kernels start their
+// accumulators at it), so results agree with them to fp32 rounding, not bit for bit.
+#include "dir_common.h"
+#include "conv_igemm.h"
+
+namespace dir {
+
+static constexpr uint32_t kOOBr = 0x80000000u;
+
+__device__ __forceinline__ void dma16r(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
+}
+
+// KB = K / 64 (2 or 4): 64-channel blocks of the input
+template <class DT, int KB>
+__global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
+    constexpr int BM = 64;                     // pixels per step
+    constexpr int BNW = 64;                    // channels per wave
+    constexpr int NT = 512;
+    constexpr int KS = KB * 4;                 // 16-wide k-slices
+    constexpr int XBUF = KB * BM * 128;        // one input tile: KB blocks of [64 px][128 B]
+    constexpr int NX = XBUF / 16 / NT;         // DMA instructions per lane per tile (KB = 4: 4)
+    constexpr int EROW = 2 * 128 + 16;         // staging row: 64 fp32 + pad
+    constexpr int EPI_OFF = 2 * XBUF;          // staging above the two input buffers
+    constexpr int BIAS_OFF = EPI_OFF + 8 * 32 * EROW;   // 512 fp32 bias values after the staging rows
+    typedef typename DT::frag_t frag_t;
+    static_assert(NX >= 1 && XBUF % (16 * NT) == 0, "tile split");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+
+    // work split: workgroup g serves channel slice g % nsl, pixel tiles (g / nsl) + i * (G / nsl)
+    const int nsl = a.Cout / 512;
+    const int mt = (a.M + BM - 1) / BM;
+    const int per = gridDim.x / nsl;           // workgroups per channel slice (launcher: G % nsl == 0)
+    const int sl = blockIdx.x % nsl;
+    int tile = blockIdx.x / nsl;
+    if (tile >= mt) return;
+    const int n_wave = sl * 512 + wave * BNW;  // first output channel of this wave
+
+    // ---- weights -> registers, once: A-fragment of channel tile i, k-slice ks ------------------
+    frag_t wf[2][KS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wf[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + i * 32 + lrow) * a.Ktot + ks * 16 +
+                                                    8 * lhi);
+
+    // Pin the weights as "already in registers": without this the compiler keeps its wait for these
+    // loads at their first use INSIDE the loop, where a vmcnt(0) would also wait for the next tile's
+    // DMA and the residual prefetch on every step.
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[i][ks]));
+
+    // ---- per-lane constants --------------------------------------------------------------------------
+    // input tile image: block kb, pixel row p, 16-byte chunk c at kb*8192 + p*128 + ((c ^ ((p>>1)&7))<<4)
+    // DMA instruction i of a lane covers linear chunk L = i*512 + tid: kb = L / 512, p = (L % 512) / 8
+    const int dchunk = (tid & 7) ^ ((tid >> 4) & 7);   // source chunk for destination slot tid & 7
+    const int dpix = (tid >> 3) & 63;                  // (NT / 8 = 64 rows per instruction = one block)
+    const int lswz = (lane >> 1) & 7;
+    const int lbase = lrow * 128;
+
+    const int ecol = (lane & 7) * 8, erow = lane >> 3;   // epilogue: 8 lanes x 8 channels per pixel row
+    // the workgroup's 512 bias values live in LDS (read back per epilogue pass: registers are all taken
+    // by weights + accumulators + the residual prefetch)
+    float* const sbias = (float*)(smem + BIAS_OFF);
+    sbias[tid] = a.bias[sl * 512 + tid];
+    const float* const bz = sbias + wave * BNW + ecol;
+
+    auto issue_x = [&](int t, char* buf) {
+        const int m = t * BM + dpix;
+        const uint32_t base = m < a.M ? (uint32_t)((m * a.Cin + dchunk * 8) * 2) : kOOBr;
+#pragma unroll
+        for (int i = 0; i < NX; ++i)   // instruction i = K block i (64 channels = 128 bytes further)
+            dma16r(rsrc_x, buf + (i * NT + wave * 64) * 16, base, i * 128);
+    };
+
+    issue_x(tile, smem);
+    int cur = 0;
+    char* const ebase = smem + EPI_OFF + wave * (32 * EROW);
+    for (;;) {
+        const int next = tile + per;
+        const bool more = next < mt;
+        // stage the NEXT pixel tile into the other buffer (its last readers finished before the
+        // barrier that ended the previous step)
+        if (more) issue_x(next, smem + (cur ^ 1) * XBUF);
+        // residual of THIS tile (64 pixels x this wave's 64 channels = 8 x 16 B per lane), fetched now so
+        // that its latency hides under the MFMAs instead of sitting between the epilogue's stores
+        const int m0 = tile * BM;
+        u32x4_t rres[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = m0 + j * 32 + pass * 8 + erow;
+                rres[j][pass] = gload16(a.res + (size_t)(m < a.M ? m : 0) * a.Cout + n_wave + ecol);
+            }
+        // Outstanding, oldest first: this tile's NX input loads, the previous tile's stores, then the
+        // loads just issued (NX for the next tile, 8 residual).  Loads return in order, so once no more
+        // than the number of YOUNGER loads is left, this tile's input has landed - while the previous
+        // tile's stores may still be draining.
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NX + 8) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();   // this tile's input has landed for every wave
+
+        const char* xb = smem + cur * XBUF;
+        // the two 32-pixel strips of the tile one after the other: 32 accumulator registers instead of 64
+        // (weights 128 + residual prefetch 32 + accumulators must stay under 256 without spilling - a
+        // spill reload is a VMEM op and would drag a vmcnt(0) into the loop)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16_t acc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const frag_t xf = *(const frag_t*)(xb + (ks >> 2) * (BM * 128) + j * (32 * 128) + lbase +
+                                                   (((2 * (ks & 3) + lhi) ^ lswz) << 4));
+                acc[0] = DT::mfma32(wf[0][ks], xf, acc[0]);
+                acc[1] = DT::mfma32(wf[1][ks], xf, acc[1]);
+            }
+            // ---- epilogue of the strip: acc -> LDS fp32 -> bias / residual / ReLU -> 16-byte stores ----
+            if (j == 0) {
+                // one wait for the whole residual prefetch (issued before the MFMAs, long landed) instead
+                // of a counted wait per pass that would also wait for this tile's own stores
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) asm volatile("" : "+v"(rres[jj][pass]));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t v = {acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+                    *(f32x4_t*)(ebase + lrow * EROW + (i * 32 + 8 * g + 4 * lhi) * 4) = v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int mrow = pass * 8 + erow;
+                const int m = m0 + j * 32 + mrow;
+                const f32x4_t f0 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4);
+                const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
+                if (m < a.M) {
+                    const f32x4_t b0 = *(const f32x4_t*)bz, b1 = *(const f32x4_t*)(bz + 4);
+                    float v[8] = {f0[0] + b0[0], f0[1] + b0[1], f0[2] + b0[2], f0[3] + b0[3],
+                                  f1[0] + b1[0], f1[1] + b1[1], f1[2] + b1[2], f1[3] + b1[3]};
+                    const size_t o = (size_t)m * a.Cout + n_wave + ecol;
+                    const u32x4_t rv = rres[j][pass];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo, hi;
+                        DT::unpack(rv[e], lo, hi);
+                        v[2 * e] += lo;
+                        v[2 * e + 1] += hi;
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    u32x4_t ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
+                    gstore16(a.y + o, ov);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (!more) break;
+        tile = next;
+        cur ^= 1;
+        // every wave must be done READING buffer `cur ^ 1` (the tile just finished) before the next
+        // step's DMA overwrites it
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+bool conv1x1_wreg_admissible(const ConvArgs& a) {
+    // (the kernel is written for the residual convs: the residual prefetch is unconditional)
+    return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
+           a.Cout % 512 == 0 && (a.Cin == 128 || a.Cin == 256) && a.res != nullptr;
+}
+
+template <class DT, int KB>
+static hipError_t launch_wreg(const ConvArgs& a, hipStream_t stream) {
+    constexpr int XBUF = KB * 64 * 128;
+    constexpr int LDS = 2 * XBUF + 8 * 32 * (2 * 128 + 16) + 512 * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv1x1_wreg_kernel<DT, KB>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvArgs b = a;
+    b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
+    b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
+    const int nsl = a.Cout / 512;
+    const int mt = (a.M + 63) / 64;
+    int per = 256 / nsl;                       // one persistent workgroup per CU
+    if (per > mt) per = mt;
+    hipLaunchKernelGGL(kern, dim3(per * nsl), dim3(512), LDS, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
+    if (a.Cin == 256)
+        return dtype == DIR_BF16 ? launch_wreg<BF16, 4>(a, stream) : launch_wreg<FP16, 4>(a, stream);
+    return dtype == DIR_BF16 ? launch_wreg<BF16, 2>(a, stream) : launch_wreg<FP16, 2>(a, stream);
+}
+
+}  // namespace dir

@@ -35,10 +35,13 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-def variant_admissible(name, Cin, Cout, k, stride, pad):
+def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
     """Mirror of conv_variant_admissible (csrc/conv_igemm.hip): igemm variants need BN | Cout; the
-    LDS-patch variants are 3x3 stride-1 pad-1 with Cin == Cout == BN."""
+    LDS-patch variants are 3x3 stride-1 pad-1 with Cin == Cout == BN; the register-stationary-weights
+    kernel is for the residual 1x1 convs with K <= 256 and Cout a multiple of 512."""
     bn = int(name.split('_')[0].split('x')[1])
+    if 'wreg1x1' in name:
+        return k == 1 and stride == 1 and pad == 0 and Cout % 512 == 0 and Cin in (128, 256) and has_res
     if 'patch3x3' in name:
         return k == 3 and stride == 1 and pad == 1 and Cin == Cout == bn
     if 'persist1x1' in name:
@@ -91,6 +94,8 @@ CONV_SHAPES = [
     ('1x1_persist_flat', 2, 24, 27, 256, 512, 1, 1, 0, True, True),
     ('1x1_persist_k128', 1, 40, 40, 128, 256, 1, 1, 0, False, True),
     ('3x3_patch128_exact', 1, 16, 64, 128, 128, 3, 1, 1, False, False),
+    ('1x1_wreg_k256', 2, 17, 13, 256, 1024, 1, 1, 0, True, True),       # 442 pixels: ragged last tile of 64
+    ('1x1_wreg_k128_norelu', 3, 20, 20, 128, 512, 1, 1, 0, True, False),
 ]
 
 
@@ -103,7 +108,7 @@ def test_conv_variant_vs_oracle(shape, variant, dname):
     names = ops.conv_variant_names()
     if variant >= len(names):
         pytest.skip('no such variant')
-    if not variant_admissible(names[variant], Cin, Cout, k, stride, pad):
+    if not variant_admissible(names[variant], Cin, Cout, k, stride, pad, use_res):
         pytest.skip('variant %s not admissible for this shape' % names[variant])
     dt = DTYPES[dname]
     x = _rand((B, H, W, Cin), 1).to(dt)
@@ -417,6 +422,8 @@ BIG_SHAPES = [  # ResNet-101 @ 1024x1024 layer shapes (B = 1): name, H, W, Cin, 
     ('layer2.1.conv2', 128, 128, 128, 128, 3, 1, 1, False),
     ('layer3.conv1', 64, 64, 1024, 256, 1, 1, 0, False),
     ('layer3.conv2', 64, 64, 256, 256, 3, 1, 1, False),
+    ('layer3.conv3', 64, 64, 256, 1024, 1, 1, 0, True),
+    ('layer2.conv3', 128, 128, 128, 512, 1, 1, 0, True),
     ('layer4.0.downsample', 64, 64, 1024, 2048, 1, 2, 0, False),
     ('layer4.conv2', 32, 32, 512, 512, 3, 1, 1, False),
 ]
@@ -436,7 +443,7 @@ def test_conv_full_size_vs_device_checker(shape):
     ref = ops.conv_bn_act(x, w, bias, res, stride=stride, pad=pad, relu=True, naive=True).float()
     names = ops.conv_variant_names()
     for v, n in enumerate(names):
-        if not variant_admissible(n, Cin, Cout, k, stride, pad):
+        if not variant_admissible(n, Cin, Cout, k, stride, pad, use_res):
             continue
         y = ops.conv_bn_act(x, w, bias, res, stride=stride, pad=pad, relu=True, variant=v).float()
         err = (y - ref).abs()
