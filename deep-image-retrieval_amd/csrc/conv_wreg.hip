@@ -50,6 +50,12 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
 
     const __amdgpu_buffer_rsrc_t rsrc_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    // residual loads and output stores go through bounds-checked descriptors too: a ragged last tile
+    // needs no branch (out-of-range rows read zeros / drop the store), and with every VMEM op of the
+    // loop unconditional the compiler's vmcnt bookkeeping is exact instead of "wait for everything"
+    const uint32_t y_bytes = (uint32_t)((size_t)a.M * a.Cout * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
 
     // work split: workgroup g serves channel slice g % nsl, pixel tiles (g / nsl) + i * (G / nsl)
     const int nsl = a.Cout / 512;
@@ -100,35 +106,35 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
             dma16r(rsrc_x, buf + (i * NT + wave * 64) * 16, base, i * 128);
     };
 
+    // residual of one 32-pixel strip (this wave's 64 channels): 4 x 16 B per lane
+    const uint32_t ncol2 = (uint32_t)((n_wave + ecol) * 2);
+    auto row_off = [&](int m) { return m < a.M ? (uint32_t)m * (uint32_t)(a.Cout * 2) + ncol2 : kOOBr; };
+    auto load_res = [&](int t, int j, u32x4_t* r) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass)
+            r[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, row_off(t * BM + j * 32 + pass * 8 + erow), 0, 0);
+    };
+
     issue_x(tile, smem);
     int cur = 0;
     char* const ebase = smem + EPI_OFF + wave * (32 * EROW);
+    // Residual prefetch, rolling: strip 0 of a tile is requested while the PREVIOUS tile computes its
+    // strip 1, strip 1 at the top of the tile's own step - each about one tile's time ahead of its use,
+    // enough for an HBM round trip under load, with 2 x 16 registers.
+    u32x4_t rres0[4], rres1[4];
+    load_res(tile, 0, rres0);
     for (;;) {
-        const int next = tile + per;
-        const bool more = next < mt;
+        const bool more = tile + per < mt;
+        const int next = more ? tile + per : tile;   // last step: harmless repeat into the idle buffer
         // stage the NEXT pixel tile into the other buffer (its last readers finished before the
         // barrier that ended the previous step)
-        if (more) issue_x(next, smem + (cur ^ 1) * XBUF);
-        // residual of THIS tile (64 pixels x this wave's 64 channels = 8 x 16 B per lane), fetched now so
-        // that its latency hides under the MFMAs instead of sitting between the epilogue's stores
+        issue_x(next, smem + (cur ^ 1) * XBUF);
         const int m0 = tile * BM;
-        u32x4_t rres[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int m = m0 + j * 32 + pass * 8 + erow;
-                rres[j][pass] = gload16(a.res + (size_t)(m < a.M ? m : 0) * a.Cout + n_wave + ecol);
-            }
-        // Outstanding, oldest first: this tile's NX input loads, the previous tile's stores, then the
-        // loads just issued (NX for the next tile, 8 residual).  Loads return in order, so once no more
-        // than the number of YOUNGER loads is left, this tile's input has landed - while the previous
-        // tile's stores may still be draining.
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NX + 8) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(8) : "memory");
-        }
+        load_res(tile, 1, rres1);
+        // Loads return in order: once no more than the 12 loads issued after this tile's input (strip 0's
+        // residual, the next tile's input, strip 1's residual) are left, the input has landed - while the
+        // previous tile's stores may still be draining.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NX + 8) : "memory");
         __builtin_amdgcn_s_barrier();   // this tile's input has landed for every wave
 
         const char* xb = smem + cur * XBUF;
@@ -148,15 +154,19 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
                                                    (((2 * (ks & 3) + lhi) ^ lswz) << 4));
                 acc[0] = DT::mfma32(wf[0][ks], xf, acc[0]);
                 acc[1] = DT::mfma32(wf[1][ks], xf, acc[1]);
+                // bound how far the compiler hoists fragment reads: every register is spoken for
+                if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             // ---- epilogue of the strip: acc -> LDS fp32 -> bias / residual / ReLU -> 16-byte stores ----
-            if (j == 0) {
-                // one wait for the whole residual prefetch (issued before the MFMAs, long landed) instead
-                // of a counted wait per pass that would also wait for this tile's own stores
+            // one wait for the strip's residual (requested long ago) instead of a counted wait per pass
+            // that would also wait for this tile's own stores
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int pass = 0; pass < 4; ++pass) asm volatile("" : "+v"(rres[jj][pass]));
+            for (int pass = 0; pass < 4; ++pass) {
+                if (j == 0) {
+                    asm volatile("" : "+v"(rres0[pass]));
+                } else {
+                    asm volatile("" : "+v"(rres1[pass]));
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -174,12 +184,11 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
                 const int m = m0 + j * 32 + mrow;
                 const f32x4_t f0 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4);
                 const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
-                if (m < a.M) {
+                {
                     const f32x4_t b0 = *(const f32x4_t*)bz, b1 = *(const f32x4_t*)(bz + 4);
                     float v[8] = {f0[0] + b0[0], f0[1] + b0[1], f0[2] + b0[2], f0[3] + b0[3],
                                   f1[0] + b1[0], f1[1] + b1[1], f1[2] + b1[2], f1[3] + b1[3]};
-                    const size_t o = (size_t)m * a.Cout + n_wave + ecol;
-                    const u32x4_t rv = rres[j][pass];
+                    const u32x4_t rv = j == 0 ? rres0[pass] : rres1[pass];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float lo, hi;
@@ -194,14 +203,18 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
                     u32x4_t ov;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
-                    gstore16(a.y + o, ov);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row_off(m), 0, 0);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (j == 0) load_res(next, 0, rres0);   // next tile's strip 0, one tile ahead
         }
-        if (!more) break;
+        if (!more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated DMA must not outlive the workgroup
+            break;
+        }
         tile = next;
         cur ^= 1;
         // every wave must be done READING buffer `cur ^ 1` (the tile just finished) before the next
