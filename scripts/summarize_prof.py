@@ -30,9 +30,12 @@ def short(name):
     m = re.search(r'conv1x1_persist_kernel<dir::(\w+)>', name)
     if m:
         return 'conv_igemm<256x256_persist1x1>[%s]' % m.group(1).lower()
-    m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)>', name)
+    m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)', name)
     if m:
         return 'conv_igemm<256x%s_patch3x3>[%s]' % (m.group(2), m.group(1).lower())
+    m = re.search(r'conv1x1_wreg_kernel<dir::(\w+), (\d+)>', name)
+    if m:
+        return 'conv_igemm<64x512_wreg1x1>[%s]' % m.group(1).lower()
     m = re.search(r'dir::(\w+)', name)
     if m:
         return m.group(1)
