@@ -28,6 +28,7 @@
 #include "dir_common.h"
 #include "conv_igemm.h"
 
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 
@@ -514,8 +515,11 @@ int conv_pick_variant(const ConvArgs& a) {
     // the residual 1x1 convs with K <= 256 (layer2/3 conv3): weights stationary in registers, as long
     // as every persistent workgroup gets at least ~4 pixel tiles to amortise loading them
     {
+        static const bool no_wreg = getenv("DIRTORCH_AMD_NO_WREG") != nullptr;   // A/B and bisecting
         const int v = find_variant("64x512_wreg1x1");
-        if (v >= 0 && conv_variant_admissible(v, a) && (long)ceil_div(a.M, 64) * (a.Cout / 512) >= 1024) return v;
+        if (!no_wreg && v >= 0 && conv_variant_admissible(v, a) &&
+            (long)ceil_div(a.M, 64) * (a.Cout / 512) >= 1024)
+            return v;
     }
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };

@@ -8,7 +8,7 @@
 // here, so a wave can simply KEEP its weights: 64 output channels x K = 256 inputs are 16 MFMA
 // A-fragments x 2 channel tiles = 128 VGPRs.  A persistent 8-wave workgroup owns 512 consecutive
 // output channels (64 per wave), loads them once, and then streams pixel tiles of 64: only the input
-// tile (32 KB for K = 256, double-buffered by LDS-DMA) is filled per step and it is shared by all
+// tile (32 KB for K = 256, double-buffered, staged through registers) is filled per step and shared by all
 // eight waves, so the input is re-read Cout/512 times instead of Cout/256 and the weights never.
 //
 // Everything else is the conv_igemm design: swapped MFMA roles (A = weights, B = pixels), XOR-swizzled
@@ -21,10 +21,6 @@
 namespace dir {
 
 static constexpr uint32_t kOOBr = 0x80000000u;
-
-__device__ __forceinline__ void dma16r(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
-}
 
 // KB = K / 64 (2 or 4): 64-channel blocks of the input
 template <class DT, int KB>
@@ -84,28 +80,37 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[i][ks]));
 
     // ---- per-lane constants --------------------------------------------------------------------------
-    // input tile image: block kb, pixel row p, 16-byte chunk c at kb*8192 + p*128 + ((c ^ ((p>>1)&7))<<4)
-    // DMA instruction i of a lane covers linear chunk L = i*512 + tid: kb = L / 512, p = (L % 512) / 8
-    const int dchunk = (tid & 7) ^ ((tid >> 4) & 7);   // source chunk for destination slot tid & 7
-    const int dpix = (tid >> 3) & 63;                  // (NT / 8 = 64 rows per instruction = one block)
+    // input tile image in LDS: block kb (64 channels), pixel row p, 16-byte chunk c at
+    //   kb*8192 + p*128 + ((c ^ ((p >> 1) & 7)) << 4)           (conv_igemm's swizzle)
+    // Staging goes through REGISTERS (buffer_load -> ds_write), not LDS-DMA: this loop keeps ordinary
+    // loads (residual prefetch) in flight next to the input prefetch, and a counted vmcnt is only a
+    // guarantee among loads that return in issue order - LDS-DMA and VGPR loads do not (measured: with
+    // the input on LDS-DMA the first tile of every workgroup was computed from a half-landed buffer).
+    // With one kind of load every wait is the compiler's own exact count.
+    const int spix = (tid >> 3) & 63;                  // pixel row this lane stages (NT / 8 = 64 rows)
+    const int sslot = tid & 7;                         // 16-byte chunk of the 128-byte row
+    const int sdst = spix * 128 + ((sslot ^ ((spix >> 1) & 7)) << 4);
     const int lswz = (lane >> 1) & 7;
     const int lbase = lrow * 128;
 
     const int ecol = (lane & 7) * 8, erow = lane >> 3;   // epilogue: 8 lanes x 8 channels per pixel row
     // the workgroup's 512 bias values live in LDS (read back per epilogue pass: registers are all taken
-    // by weights + accumulators + the residual prefetch)
+    // by weights + accumulators + the prefetches)
     float* const sbias = (float*)(smem + BIAS_OFF);
     sbias[tid] = a.bias[sl * 512 + tid];
     const float* const bz = sbias + wave * BNW + ecol;
 
-    auto issue_x = [&](int t, char* buf) {
-        const int m = t * BM + dpix;
-        const uint32_t base = m < a.M ? (uint32_t)((m * a.Cin + dchunk * 8) * 2) : kOOBr;
+    // input tile t -> NX registers per lane (block i = channels 64 i ..; out-of-range rows read zeros)
+    auto load_x = [&](int t, u32x4_t* xr) {
+        const int m = t * BM + spix;
+        const uint32_t base = m < a.M ? (uint32_t)((m * a.Cin + sslot * 8) * 2) : kOOBr;
 #pragma unroll
-        for (int i = 0; i < NX; ++i)   // instruction i = K block i (64 channels = 128 bytes further)
-            dma16r(rsrc_x, buf + (i * NT + wave * 64) * 16, base, i * 128);
+        for (int i = 0; i < NX; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, i * 128, 0);
     };
-
+    auto store_x = [&](const u32x4_t* xr, char* buf) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) *(u32x4_t*)(buf + i * (BM * 128) + sdst) = xr[i];
+    };
     // residual of one 32-pixel strip (this wave's 64 channels): 4 x 16 B per lane
     const uint32_t ncol2 = (uint32_t)((n_wave + ecol) * 2);
     auto row_off = [&](int m) { return m < a.M ? (uint32_t)m * (uint32_t)(a.Cout * 2) + ncol2 : kOOBr; };
@@ -115,7 +120,8 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
             r[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, row_off(t * BM + j * 32 + pass * 8 + erow), 0, 0);
     };
 
-    issue_x(tile, smem);
+    u32x4_t xr[NX];
+    load_x(tile, xr);
     int cur = 0;
     char* const ebase = smem + EPI_OFF + wave * (32 * EROW);
     // Residual prefetch, rolling: strip 0 of a tile is requested while the PREVIOUS tile computes its
@@ -123,19 +129,14 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     // enough for an HBM round trip under load, with 2 x 16 registers.
     u32x4_t rres0[4], rres1[4];
     load_res(tile, 0, rres0);
+    store_x(xr, smem);
+    __builtin_amdgcn_s_barrier();   // first tile staged (and the bias table written)
     for (;;) {
         const bool more = tile + per < mt;
-        const int next = more ? tile + per : tile;   // last step: harmless repeat into the idle buffer
-        // stage the NEXT pixel tile into the other buffer (its last readers finished before the
-        // barrier that ended the previous step)
-        issue_x(next, smem + (cur ^ 1) * XBUF);
+        const int next = more ? tile + per : tile;   // last step: a harmless repeat
+        load_x(next, xr);                            // lands during this tile's MFMAs
         const int m0 = tile * BM;
         load_res(tile, 1, rres1);
-        // Loads return in order: once no more than the 12 loads issued after this tile's input (strip 0's
-        // residual, the next tile's input, strip 1's residual) are left, the input has landed - while the
-        // previous tile's stores may still be draining.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NX + 8) : "memory");
-        __builtin_amdgcn_s_barrier();   // this tile's input has landed for every wave
 
         const char* xb = smem + cur * XBUF;
         // the two 32-pixel strips of the tile one after the other: 32 accumulator registers instead of 64
@@ -211,14 +212,12 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (j == 0) load_res(next, 0, rres0);   // next tile's strip 0, one tile ahead
         }
-        if (!more) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated DMA must not outlive the workgroup
-            break;
-        }
+        if (!more) break;
+        // publish the next tile: its buffer was last read one step ago (every wave has passed that step's
+        // barrier since), and this barrier also closes the reads of the buffer just used
+        store_x(xr, smem + (cur ^ 1) * XBUF);
         tile = next;
         cur ^= 1;
-        // every wave must be done READING buffer `cur ^ 1` (the tile just finished) before the next
-        // step's DMA overwrites it
         __builtin_amdgcn_s_barrier();
     }
 }

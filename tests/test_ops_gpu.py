@@ -455,3 +455,40 @@ def test_conv_full_size_vs_device_checker(shape):
     y1 = ops.conv_bn_act(x, w, zero, None, stride=stride, pad=pad, relu=False).float()
     y2 = ops.conv_bn_act((x.float() * 2).to(dt), w, zero, None, stride=stride, pad=pad, relu=False).float()
     assert torch.equal(y2, y1 * 2)
+
+
+@pytest.mark.parametrize('shape', [(63, 128, 128, 512), (8, 128, 128, 512), (8, 64, 256, 1024)],
+                         ids=lambda s: 'B%d_%d_K%d_N%d' % s)
+def test_wreg_persistent_kernel_first_tiles_at_scale(shape):
+    """Regression: the register-stationary 1x1 kernel at network scale (256 persistent workgroups, all
+    tensors carved from one workspace, a busy kernel right before it).  An earlier version staged its
+    input with LDS-DMA next to ordinary prefetch loads and trusted a counted vmcnt across the two kinds:
+    the first tile of every workgroup was then computed from a half-landed buffer, but only at some
+    sizes and only inside the network."""
+    ops = _ops()
+    from dirtorch_amd import _lib
+    names = ops.conv_variant_names()
+    vw, vi = names.index('64x512_wreg1x1'), names.index('128x256_w2x4_s3_k32')
+    B, H, Cin, Cout = shape
+
+    def call(x, w, b, r, y, variant):
+        _lib.call('dir_conv_bn_act', _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), B, H, H, Cin,
+                  Cout, 1, 1, 1, 0, H, H, 1, 0, variant, _lib.stream_ptr())
+
+    g = torch.Generator(device='cuda').manual_seed(1)
+    n_x, n_y = B * H * H * Cin, B * H * H * Cout
+    ws = torch.empty(n_x + 3 * n_y, dtype=torch.bfloat16, device='cuda')
+    x = ws[:n_x].view(B, H, H, Cin)
+    r, y1, y2 = (ws[n_x + i * n_y:n_x + (i + 1) * n_y].view(B, H, H, Cout) for i in range(3))
+    x.copy_(torch.relu(torch.randn(B, H, H, Cin, generator=g, device='cuda')).to(torch.bfloat16))
+    r.copy_(torch.relu(torch.randn(B, H, H, Cout, generator=g, device='cuda')).to(torch.bfloat16))
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g, device='cuda') * 0.05).to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g, device='cuda') * 0.1
+    call(x, w, b, r, y2, vi)
+    for rep in range(6):
+        y1.fill_(float('nan'))
+        call(x, w, b, r, y2, vi)
+        call(x, w, b, r, y1, vw)
+        d = (y1.float() - y2.float()).abs()
+        assert bool(torch.isfinite(y1.float()).all()), rep
+        assert float(d.max()) <= 2 * RTOL['bf16'] * float(y2.float().abs().max()), (rep, float(d.max()))
