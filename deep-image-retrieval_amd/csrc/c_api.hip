@@ -247,6 +247,29 @@ int dir_conv_variant_name(int variant, char* buf, int cap) {
 
 static int fill_conv_args(ConvArgs& a, const void* x, const void* w, const float* bias,
                           const void* res, void* y, int B, int H, int W, int Cin, int Cout, int R,
+                          int S, int stride, int pad, int OH, int OW, int relu);
+
+int dir_conv_heuristic(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int OH,
+                       int OW, int has_residual, char* name, int cap, int* ksplit) {
+    DIR_TRY
+    if (!name || cap <= 0) return fail(DIR_ERR_INVALID, "conv_heuristic: null name buffer");
+    ConvArgs a;
+    // host-only decision: the pointers are never dereferenced, they only have to be non-null
+    static const float dummy = 0.f;
+    int rc = fill_conv_args(a, &dummy, &dummy, &dummy, has_residual ? &dummy : nullptr, (void*)&dummy, B, H, W, Cin,
+                            Cout, R, S, stride, pad, OH, OW, 1);
+    if (rc != DIR_OK) return rc;
+    const int v = conv_pick_variant(a);
+    if (v < 0) return fail(DIR_ERR_INVALID, "conv_heuristic: no admissible variant for this shape");
+    strncpy(name, conv_variant(v).name, cap - 1);
+    name[cap - 1] = 0;
+    if (ksplit) *ksplit = conv_splitk_factor(v, a);
+    return DIR_OK;
+    DIR_CATCH
+}
+
+static int fill_conv_args(ConvArgs& a, const void* x, const void* w, const float* bias,
+                          const void* res, void* y, int B, int H, int W, int Cin, int Cout, int R,
                           int S, int stride, int pad, int OH, int OW, int relu) {
     if (!x || !w || !bias || !y) return fail(DIR_ERR_INVALID, "conv: null pointer");
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 ||

@@ -147,6 +147,11 @@ int dir_conv_variant_name(int variant, char* buf, int cap);
 int dir_conv_bn_act(const void* x, const void* w, const float* bias, const void* res, void* y,
                     int B, int H, int W, int Cin, int Cout, int R, int S, int stride,
                     int pad, int OH, int OW, int relu, int dtype, int variant, void* stream);
+/* Which tile variant (and split-K factor) the engine picks for a layer shape that has not been autotuned.
+ * Pure host logic - no GPU needed - exposed so that the choices distilled from the tuner stay pinned by
+ * CPU tests (tests/test_capi_host.py). */
+int dir_conv_heuristic(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int OH,
+                       int OW, int has_residual, char* name, int cap, int* ksplit);
 /* Same convolution with the K loop cut into `ksplit` slices that run as separate workgroups and meet in
  * an fp32 scratch buffer (ksplit * B*OH*OW * Cout floats; slices are added in a fixed order, then bias /
  * residual / ReLU) - what the engine does for layers with too few output tiles to fill 256 CUs (batch 1

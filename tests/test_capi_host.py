@@ -94,3 +94,44 @@ def test_no_cpu_execution_path():
             net.cuda()
         with pytest.raises((RuntimeError, Exception)):
             net(torch.zeros(1, 3, 64, 64))
+
+
+def test_tile_heuristic_choices_for_resnet101_at_1024():
+    """The tile variant the engine picks for un-tuned shapes is what every default run uses (bench.py
+    included).  Pin the choices for the ResNet-101 @ 1024^2 layer shapes at batch 32 and batch 1 - they
+    were distilled from the autotuner and A/B runs on the GPU; a silent change here
+    is a performance regression no numerics test would catch.  Pure host logic: runs without a GPU."""
+    import ctypes
+    from dirtorch_amd import _lib
+
+    def pick(B, H, Cin, Cout, k, stride, res):
+        pad = 1 if k == 3 else 0
+        OH = (H + 2 * pad - k) // stride + 1
+        buf, ks = ctypes.create_string_buffer(64), ctypes.c_int()
+        _lib.call('dir_conv_heuristic', B, H, H, Cin, Cout, k, k, stride, pad, OH, OH, int(res), buf, 64,
+                  ctypes.byref(ks))
+        return buf.value.decode(), ks.value
+
+    shapes = {   # name: (H of the input map, Cin, Cout, k, stride, residual)
+        'l1.conv1': (256, 256, 64, 1, 1, 0), 'l1.conv2': (256, 64, 64, 3, 1, 0), 'l1.conv3': (256, 64, 256, 1, 1, 1),
+        'l2.conv1': (128, 512, 128, 1, 1, 0), 'l2.conv2': (128, 128, 128, 3, 1, 0), 'l2.conv3': (128, 128, 512, 1, 1, 1),
+        'l3.conv1': (64, 1024, 256, 1, 1, 0), 'l3.conv2': (64, 256, 256, 3, 1, 0), 'l3.conv3': (64, 256, 1024, 1, 1, 1),
+        'l4.conv1': (32, 2048, 512, 1, 1, 0), 'l4.conv2': (32, 512, 512, 3, 1, 0), 'l4.conv3': (32, 512, 2048, 1, 1, 1),
+    }
+    batch32 = {
+        'l1.conv1': '256x64_w4x1', 'l1.conv2': '256x64_patch3x3', 'l1.conv3': '256x64_w4x1',
+        'l2.conv1': '256x128_w4x2_s3_k32', 'l2.conv2': '256x128_w4x2_s3_k32', 'l2.conv3': '64x512_wreg1x1',
+        'l3.conv1': '256x256_persist1x1', 'l3.conv2': '256x256_w4x4', 'l3.conv3': '64x512_wreg1x1',
+        'l4.conv1': '256x256_persist1x1', 'l4.conv2': '256x256_w4x4', 'l4.conv3': '256x256_persist1x1',
+    }
+    for name, s in shapes.items():
+        assert pick(32, *s) == (batch32[name], 1), name
+    batch1 = {    # small M: deep-ring small tiles, split-K where even those leave CUs idle
+        'l2.conv2': ('64x128_w2x2_s4', 1), 'l3.conv1': ('64x128_w2x2_s4', 1), 'l3.conv2': ('64x128_w2x2_s4', 1),
+        'l3.conv3': ('128x128_w2x2', 1), 'l4.conv1': ('64x128_w2x2', 8), 'l4.conv2': ('64x128_w2x2', 8),
+    }
+    for name, want in batch1.items():
+        assert pick(1, *shapes[name]) == want, name
+    # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
+    assert pick(32, 64, 256, 1024, 1, 1, 0)[0] != '64x512_wreg1x1'
+    assert pick(2, 64, 256, 1024, 1, 1, 1)[0] != '64x512_wreg1x1'
