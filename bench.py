@@ -10,11 +10,13 @@ of synthetic normalised images that is already resident in HBM.  Database images
 image-parallel over the ranks (no data-path collective inside a step); after the K steps each rank
 all-gathers its shard's descriptor block once over RCCL/xGMI (the one exchange step the path has,
 inside the timed region for N > 1).  Weights are the deterministic synthetic checkpoint of
-oracle/dir_oracle.py (there is no network for real ones).
+tests/synth.py (there is no network for real ones); oracle/ is imported by the cpu_baseline leg only.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel family (implicit-GEMM conv), algorithmic FLOPs / event-timed
-                launch durations collected inside this process over the timed steps
+  roofline      the kernel with the largest time share (bound / achieved / peak / frac / traffic) AND
+                `kernels`: the same figures for every (kernel, layer shape) group of the step, plus the
+                step-level MFMA fraction - algorithmic FLOPs and bytes / event-timed launch durations
+                collected inside this process over the timed steps
   cpu_baseline  the CPU oracle (a port of the reference forward) timed on this box's host cores
                 on a bounded sample of the same workload (rank 0, N == 1 only)
 """
@@ -25,7 +27,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'oracle')):
+for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -39,19 +41,37 @@ PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.29 TB/s measure
 GFLOP_PER_IMG = {('resnet101', 1024): 325.99, ('resnet50', 224): 8.183}
 
 
-def cpu_baseline(arch, size, budget_s):
-    """CPU oracle forward, batch 1 (the reference's default path, test_dir.py:52-55), all cores."""
-    import dir_oracle as O
-    sd = O.synth_state_dict(arch, seed=7)
-    # thread count: the box may expose more logical CPUs than its cgroup lets run; pick the
-    # fastest of a few counts on a 256x256 probe (a few hundred ms each) instead of trusting nproc
+def cpu_allotted():
+    """CPUs this process may actually use: the cgroup quota when there is one, else the affinity mask."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    probe = O.synth_images(11, 1, 256, 256)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            avail = min(avail, max(1, int(round(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def cpu_baseline(arch, size, budget_s):
+    """CPU oracle forward, batch 1 (the reference's default path, test_dir.py:52-55), all cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import dir_oracle as O          # the only oracle import of this file: the timed CPU port
+    import synth
+    sd = synth.synth_state_dict(arch, seed=7)
+    # thread count: the box may expose more logical CPUs than its cgroup lets run; pick the
+    # fastest of a few counts on a probe at half the image side instead of trusting nproc
+    allotted = cpu_allotted()
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    probe = synth.synth_images(11, 1, max(size // 2, 64), max(size // 2, 64))
     best = (float('inf'), 1)
-    for nt in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
+    for nt in sorted({min(visible, c) for c in (allotted // 2 or 1, allotted, 2 * allotted)}):
         torch.set_num_threads(nt)
         O.rmac_forward(sd, arch, probe)
         t0 = time.perf_counter()
@@ -59,10 +79,8 @@ def cpu_baseline(arch, size, budget_s):
         dt = time.perf_counter() - t0
         if dt < best[0]:
             best = (dt, nt)
-        if dt > 4 * best[0] or dt > 5.0:
-            break
     torch.set_num_threads(best[1])
-    x = O.synth_images(11, 1, size, size)
+    x = synth.synth_images(11, 1, size, size)
     O.rmac_forward(sd, arch, x)   # warm-up (allocator, oneDNN primitive cache)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -72,8 +90,49 @@ def cpu_baseline(arch, size, budget_s):
         if el >= budget_s or n >= 64:
             break
     return {'value': round(n / el, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
-            'kind': 'port',
+            'cpu_allotted': allotted, 'cpu_visible': visible, 'kind': 'port',
             'sample': '%d x %s fp32 %dx%d forward, batch 1, oracle/dir_oracle.py (%.1f s)' % (n, arch, size, size, el)}
+
+
+def layer_group(name):
+    """'layer3.7.conv2' -> 'layer3.conv2' (the 23 identical blocks of a stage share a row); the first
+    block of a stage differs in shape (stride / width) and keeps its own rows through (flops, bytes)."""
+    parts = name.split('.')
+    if len(parts) == 3 and parts[0].startswith('layer'):
+        return parts[0] + '.' + parts[2]
+    return name
+
+
+def kernel_table(prof, nprof, peak_tf, traffic):
+    """One row per (kernel, layer group, algorithmic flops, bytes): launches per step, average
+    duration, share of the step, achieved TFLOP/s and GB/s, the roof that bounds it (arithmetic
+    intensity vs 2.5 PF / 8 TB/s = 312 FLOP/B) and the fraction of that roof."""
+    groups = {}
+    total = sum(r['ms'] for r in prof)
+    for r in prof:
+        key = (r['kernel'], layer_group(r['name']), r['flops'], r['bytes'])
+        g = groups.setdefault(key, [0.0, 0])
+        g[0] += r['ms']
+        g[1] += 1
+    rows = []
+    balance = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    for (kern, grp, fl, by), (ms, n) in groups.items():
+        avg = ms / n
+        tf = fl / (avg * 1e-3) / 1e12 if fl else 0.0
+        gbs = by / (avg * 1e-3) / 1e9 if by else 0.0
+        hbm = (fl / by) < balance if (fl and by) else True
+        row = {'kernel': kern, 'layers': grp, 'launches_per_step': round(n / nprof, 2), 'avg_ms': round(avg, 5),
+               'share': round(ms / total, 4), 'gflop': round(fl / 1e9, 2), 'mbytes': round(by / 1e6, 1),
+               'tflops': round(tf, 1), 'gbs': round(gbs, 1), 'bound': 'hbm' if hbm else 'mfma',
+               'frac': round(gbs / PEAK_HBM_GBS if hbm else tf / peak_tf, 4)}
+        t = (traffic or {}).get(kern)
+        if isinstance(t, dict):          # per-shape PMC traffic keyed by layer group (scripts/summarize_prof.py)
+            t = t.get(grp)
+        if t and by:
+            row['pmc_traffic_ratio'] = round(t / by, 3)
+        rows.append(row)
+    rows.sort(key=lambda r: -r['share'])
+    return rows
 
 
 def main():
@@ -93,6 +152,9 @@ def main():
     ap.add_argument('--profile-every', type=int, default=4,
                     help='record per-launch HIP events on every n-th timed step (1 = all steps)')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer profile to stderr')
+    ap.add_argument('--dump-launches', default='',
+                    help='write the launch sequence of one forward (name, kernel, flops, bytes, avg ms) as JSON: '
+                         'scripts/summarize_prof.py aligns rocprofv3 dispatches with it')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -109,10 +171,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
 
-    import dir_oracle as O
+    import synth
     from dirtorch_amd import nets
     net = nets.create_model(args.arch + '_rmac', pretrained='')
-    net.load_state_dict(O.synth_state_dict(args.arch, seed=7))
+    net.load_state_dict(synth.synth_state_dict(args.arch, seed=7))
     net.compute_dtype = args.dtype
     net.cuda().eval()
 
@@ -170,27 +232,50 @@ def main():
         # which roof bounds the dominant kernel: its arithmetic intensity vs the machine balance
         # (2.5 PF dense / 8 TB/s = 312 FLOP/B; MI355X_MICROARCH.md)
         hbm_bound = (dfl / dby) < (peak_tf * 1e12) / (PEAK_HBM_GBS * 1e9)
-        traffic = None
+        traffic_all = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # PMC-derived HBM bytes / launch (scripts/summarize_prof.py)
         if os.path.isfile(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom)
+                traffic_all = json.load(open(tfile))
             except Exception:
-                traffic = None
+                traffic_all = None
+        traffic = (traffic_all or {}).get(dom)
+        if isinstance(traffic, dict):        # per-shape entries: average over the kernel's launch mix of this step
+            per = {}
+            for r in prof:
+                if r['kernel'] == dom:
+                    per[layer_group(r['name'])] = per.get(layer_group(r['name']), 0) + 1
+            tot = sum(per.values())
+            traffic = sum(traffic.get(g, 0.0) * n for g, n in per.items()) / tot if tot and all(g in traffic for g in per) else None
+        all_ms = sum(v[0] for v in fam.values())
+        all_fl = sum(v[1] for v in fam.values())
         roof = {'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': dom,
                 'achieved': round(gbs if hbm_bound else tflops, 2),
                 'peak': PEAK_HBM_GBS if hbm_bound else peak_tf,
                 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                 'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / peak_tf, 4),
                 'traffic': traffic,
+                'note': 'frac is the largest-time-share kernel against ITS roof; the whole step is step_mfma_frac of '
+                        'the dense MFMA peak (per-kernel rows in kernels[])',
                 'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
                 'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
                 'kernel_tflops': round(tflops, 2), 'kernel_gbs': round(gbs, 1),
                 'all_conv_tflops': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                 'all_conv_mfma_frac': round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
+                'step_mfma_frac': round(all_fl / (all_ms * 1e-3) / 1e12 / peak_tf, 4),
                 'profiled_steps': nprof,
                 'all_conv_ms_per_step': round(conv_ms / nprof, 4),
-                'all_kernels_ms_per_step': round(sum(v[0] for v in fam.values()) / nprof, 4)}
+                'all_kernels_ms_per_step': round(all_ms / nprof, 4),
+                'kernels': kernel_table(prof, nprof, peak_tf, traffic_all)}
+        if args.dump_launches:
+            first = [r for r in prof]
+            L = next((i for i in range(1, len(first)) if first[i]['name'] == first[0]['name']), len(first))
+            seq = []
+            for i in range(L):
+                same = [prof[j] for j in range(i, len(prof), L)]
+                seq.append({'name': prof[i]['name'], 'kernel': prof[i]['kernel'], 'flops': prof[i]['flops'],
+                            'bytes': prof[i]['bytes'], 'ms': sum(r['ms'] for r in same) / len(same)})
+            json.dump(seq, open(args.dump_launches, 'w'), indent=0)
         if args.layers:
             agg = {}
             for r in prof:

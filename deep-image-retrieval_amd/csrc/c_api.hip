@@ -453,6 +453,30 @@ int dir_rank_counts(const float* scores, int lds, int Q, int N, const int* probe
     DIR_CATCH
 }
 
+int dir_revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* probe_scores,
+                     const int* pos_off, const int* pos_list, const int* junk_off, const int* junk_list,
+                     int modes, double* terms, double* ap_out, void* stream) {
+    DIR_TRY
+    if (Q < 0 || P < 0 || modes < 0) return fail(DIR_ERR_INVALID, "revisitop_ap: negative size");
+    if (Q == 0 || modes == 0) return DIR_OK;
+    if (!probe_idx || !counts || !probe_scores || !pos_off || !pos_list || !junk_off || !junk_list || !terms ||
+        !ap_out)
+        return fail(DIR_ERR_INVALID, "revisitop_ap: null pointer");
+    return revisitop_ap(probe_idx, Q, P, counts, probe_scores, pos_off, pos_list, junk_off, junk_list, modes,
+                        terms, ap_out, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_expand_descriptors(const float* descs, int n, const float* db, int m, int D, int k, float alpha,
+                           int self_set, float* out, float* sim, size_t sim_bytes, void* stream) {
+    DIR_TRY
+    if (n < 0 || m < 0 || D <= 0) return fail(DIR_ERR_INVALID, "expand_descriptors: bad size");
+    if (n == 0) return DIR_OK;
+    if (!descs || !db || !out || !sim) return fail(DIR_ERR_INVALID, "expand_descriptors: null pointer");
+    return expand_descriptors(descs, n, db, m, D, k, alpha, self_set, out, sim, sim_bytes, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                         void* stream) {
     DIR_TRY

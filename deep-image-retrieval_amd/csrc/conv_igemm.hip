@@ -393,13 +393,8 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
     b.T = a.Ktot / BK;
     b.tiles_m = ceil_div(a.M, BM);

@@ -228,13 +228,8 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = (256 + 256) * 128 + 8 * 32 * (2 * 128 + 16);  // slot 0 + staging (covers slot 1)
     static_assert(LDS >= 2 * (256 + 256) * 128 && LDS <= 160 * 1024, "LDS map");
     auto kern = conv1x1_persist_kernel<DT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
     b.T = a.Ktot / 64;
     b.tiles_m = ceil_div(a.M, 256);

@@ -234,12 +234,8 @@ static hipError_t launch_wreg(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * XBUF + 8 * 32 * (2 * 128 + 16) + 512 * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_wreg_kernel<DT, KB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/dir_engine.h"
@@ -126,5 +127,18 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// One-time opt-in of a kernel to more than 64 KiB of dynamic LDS, PER DEVICE (one engine per GPU may
+// live in the same process) and safe against concurrent first launches from several host threads.
+inline hipError_t ensure_dynamic_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 }  // namespace dir

@@ -390,6 +390,12 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
         (void)hipEventDestroy(e1);
         L.tuned[a.M] = variant;
     }
+    // a tuning table written for another architecture shares layer names (resnet18 / resnet101 both
+    // have layer1.0.conv1): an entry that does not fit this layer's shape is dropped, not an error
+    if (variant >= 0 && !conv_variant_admissible(variant, a)) {
+        L.tuned.erase(a.M);
+        variant = -1;
+    }
     if (variant < 0) variant = conv_pick_variant(a);
     a.ksplit = conv_splitk_factor(variant, a);
     int rc = prof_begin(L.name, std::string("conv_igemm<") + conv_variant(variant).name +

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
                                                          const float* __restrict__ qsub,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ alpha,
-                                                         int tiles_i) {
+                                                         int tiles_i, int vec_ok) {
     constexpr int BI = 128, BJ = 32 * TJ;
     constexpr int PS = BI * 128;              // bytes of one P slab (128 rows x 32 floats)
     constexpr int STAGE_BYTES = (BI + BJ) * 128;
@@ -45,23 +45,38 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
     const int prow = tid >> 3;                     // + 32 * i
 
     f32x4_t pr[4], qr[TJ];
+    // vec_ok (K, ldp, ldq multiples of 4 and 16-byte aligned bases): 16-byte loads.  Otherwise - an odd
+    // descriptor width such as --whitenv 50 (dirtorch/test_dir.py:210, common.py:226) - the same slab
+    // is gathered element by element with the K tail zero-filled; the arithmetic is unchanged.
+    auto load4 = [&](const float* base, size_t row_off, int k, bool ok) -> f32x4_t {
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (!ok) return v;
+        if (vec_ok) return *(const DIR_GLOBAL f32x4_t*)(base + row_off + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k + e < K) v[e] = base[row_off + k + e];
+        return v;
+    };
     auto fetch = [&](int k0) {
         const int k = k0 + srcchunk * 4;
-        const bool kok = k < K;  // K % 4 == 0
+        const bool kok = k < K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i0 + i * 32 + prow;
-            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-            if (kok && row < NP) v = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)row * ldp + k);
-            pr[i] = v;
+            pr[i] = load4(P, (size_t)row * ldp, k, kok && row < NP);
         }
-        f32x4_t sub = {0.f, 0.f, 0.f, 0.f};
-        if (qsub && kok) sub = *(const DIR_GLOBAL f32x4_t*)(qsub + k);
+        const f32x4_t sub = load4(qsub, 0, k, qsub != nullptr && kok);
 #pragma unroll
         for (int i = 0; i < TJ; ++i) {
             const int row = j0 + i * 32 + prow;
-            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-            if (kok && row < NQ) v = *(const DIR_GLOBAL f32x4_t*)(Q + (size_t)row * ldq + k) - sub;
+            const bool ok = kok && row < NQ;
+            f32x4_t v = load4(Q, (size_t)row * ldq, k, ok);
+            if (ok) v = v - sub;
+            if (!vec_ok && ok) {   // keep the zero-filled K tail zero (0 - sub would leak the mean in)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e >= K) v[e] = 0.f;
+            }
             qr[i] = v;
         }
     };
@@ -144,7 +159,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
                 }
             }
             float* dst = out + (size_t)jj * ldo + ii;
-            if (ii + 3 < NP && ((ldo & 3) == 0)) {
+            if (ii + 3 < NP && ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0)) {
                 *(DIR_GLOBAL f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
             } else {
 #pragma unroll
@@ -229,11 +244,13 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
         DIR_HIP_CHECK(hipGetLastError());
         return DIR_OK;
     }
-    if (K <= 0 || (K & 3) || (ldp & 3) || (ldq & 3))
-        return fail(DIR_ERR_INVALID, "gemm_nt_f32: K, ldp, ldq must be positive multiples of 4");
-    if (((uintptr_t)P & 15) || ((uintptr_t)Q & 15) || ((uintptr_t)out & 15) ||
-        (qsub && ((uintptr_t)qsub & 15)))
-        return fail(DIR_ERR_INVALID, "gemm_nt_f32: operands must be 16-byte aligned");
+    if (K <= 0 || ldp < K || ldq < K || ldo < NP)
+        return fail(DIR_ERR_INVALID, "gemm_nt_f32: K must be positive and ldp, ldq >= K, ldo >= NP");
+    if (((uintptr_t)P & 3) || ((uintptr_t)Q & 3) || ((uintptr_t)out & 3) || (qsub && ((uintptr_t)qsub & 3)))
+        return fail(DIR_ERR_INVALID, "gemm_nt_f32: operands must be 4-byte aligned");
+    // 16-byte loads when the layout allows them; any other K / pitch takes the element-wise gather
+    const int vec_ok = !(K & 3) && !(ldp & 3) && !(ldq & 3) && !((uintptr_t)P & 15) && !((uintptr_t)Q & 15) &&
+                       !(qsub && ((uintptr_t)qsub & 15));
     const int tiles_i = ceil_div(NP, 128);
     // Q tile: as wide as needed up to 128 rows, then loop tiles over j.
     int tj = NQ >= 97 ? 4 : (NQ >= 65 ? 3 : (NQ >= 33 ? 2 : 1));
@@ -242,7 +259,7 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
     if (nblk >= (1L << 31)) return fail(DIR_ERR_INVALID, "gemm_nt_f32: grid too large");
 #define DIR_G(TJ)                                                                              \
     hipLaunchKernelGGL(gemm_nt_f32_kernel<TJ>, dim3((unsigned)nblk), dim3(256), 0, stream, P,  \
-                       ldp, Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, tiles_i)
+                       ldp, Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, tiles_i, vec_ok)
     switch (tj) {
         case 1: DIR_G(1); break;
         case 2: DIR_G(2); break;

@@ -22,6 +22,11 @@ int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y,
                      int OH, int OW, int dtype, hipStream_t stream);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
+int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* pscores, const int* pos_off,
+                 const int* pos_list, const int* junk_off, const int* junk_list, int modes, double* terms,
+                 double* ap_out, hipStream_t stream);
+int expand_descriptors(const float* descs, int n, const float* db, int m, int D, int k, float alpha,
+                       int self_set, float* out, float* sim, size_t sim_bytes, hipStream_t stream);
 int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
                 int NQ, int K, const float* qsub, const float* bias, const float* alpha,
                 hipStream_t stream);

@@ -90,6 +90,10 @@ SIGNATURES = {
     'dir_similarity': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dir_rank_counts': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p]),
+    'dir_revisitop_ap': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'dir_expand_descriptors': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     'dir_multiscale_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                     c_void_p]),
 }

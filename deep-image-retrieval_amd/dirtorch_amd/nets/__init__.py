@@ -61,7 +61,6 @@ def load_pretrained_weights(net, state_dict, delete_fc=False):
             merged[name] = own
         else:
             merged[name] = cand
+    # delete_fc: the reference deletes fc.* from its LOCAL new_dict after the merge (nets/__init__.py:90-93),
+    # which changes nothing the caller can see; the caller's state_dict is left alone here too
     net.load_state_dict(merged)
-    if delete_fc:   # reference quirk kept: the caller's dict loses the FC entries
-        for suffix in ('.weight', '.bias'):
-            state_dict.pop(net.fc_name + suffix, None)

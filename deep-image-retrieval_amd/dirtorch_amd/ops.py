@@ -205,10 +205,41 @@ def rank_counts(scores, probe_idx):
         raise TypeError('float32 scores and int32 probe indices expected')
     Q, N = scores.shape
     P = probe_idx.shape[1]
-    counts = torch.zeros(Q, P, dtype=torch.int32, device=scores.device)
+    counts = torch.empty(Q, P, dtype=torch.int32, device=scores.device)    # zeroed by the call
     pscores = torch.zeros(Q, P, dtype=torch.float32, device=scores.device)
     call('dir_rank_counts', ptr(scores), N, Q, N, ptr(probe_idx), P, ptr(counts), ptr(pscores), stream_ptr())
     return counts, pscores
+
+
+def revisitop_ap(probe_idx, counts, pscores, pos_off, pos_list, junk_off, junk_list, modes):
+    """APs of every (query, mode) from the outputs of rank_counts (dir_revisitop_ap): returns a CUDA
+    float64 tensor [Q, modes], -1 where a mode has no positive.  pos_* / junk_* are CSR lists of
+    positions into the rows of probe_idx (int32 CUDA tensors)."""
+    _need_cuda(probe_idx, counts, pscores, pos_off, pos_list, junk_off, junk_list)
+    Q, P = probe_idx.shape
+    ap = torch.empty(Q, modes, dtype=torch.float64, device=probe_idx.device)
+    terms = torch.empty(max(int(pos_list.numel()), 1), dtype=torch.float64, device=probe_idx.device)
+    call('dir_revisitop_ap', ptr(probe_idx), Q, P, ptr(counts), ptr(pscores), ptr(pos_off), ptr(pos_list),
+         ptr(junk_off), ptr(junk_list), int(modes), ptr(terms), ptr(ap), stream_ptr())
+    return ap
+
+
+def expand_descriptors(descs, db=None, alpha=0.0, k=0, scratch_bytes=256 << 20):
+    """alpha-QE / DBA on the device (dir_expand_descriptors): descs [n,D], db [m,D] fp32 CUDA (db None =
+    expand the set against itself, a row never being its own neighbour) -> [n,D] fp32 CUDA."""
+    _need_cuda(descs, db)
+    self_set = db is None
+    pool_ = descs if self_set else db
+    n, D = descs.shape
+    m = pool_.shape[0]
+    out = torch.empty_like(descs)
+    if n == 0:
+        return out
+    rows = max(1, min(n, scratch_bytes // max(4 * m, 1)))
+    sim = torch.empty(rows * m, dtype=torch.float32, device=descs.device)
+    call('dir_expand_descriptors', ptr(descs), n, ptr(pool_), m, D, int(k), float(alpha), int(self_set),
+         ptr(out), ptr(sim), sim.numel() * 4, stream_ptr())
+    return out
 
 
 def stem_pool(s2d, w_packed, bias, out_hw):

@@ -2,15 +2,14 @@
 
 Same numbers as `[db.eval_query_AP(q, s) for q, s in enumerate(scores)]`
 (dirtorch/test_dir.py:153, dirtorch/datasets/generic.py:196-224) without downloading the Q x N score
-matrix or sorting it: the kernel counts, for every listed image of every query, how many database
-items rank before it; junk corrections and the AP sum touch only those few hundred listed images
-and run on the host.  Ties rank by descending index (np.argsort(...)[::-1] with a stable order).
+matrix or sorting it: one kernel counts, for every listed image of every query, how many database
+items rank before it; a second one applies the junk corrections among those few hundred listed images
+and sums the AP in fp64 in the reference's order.  Ties rank by descending index (np.argsort(...)[::-1] with a stable order).
 """
 import numpy as np
 import torch
 
 from . import ops
-from .datasets import compute_average_precision
 
 
 def similarity_device(qdescs, bdescs):
@@ -19,68 +18,59 @@ def similarity_device(qdescs, bdescs):
     return ops.gemm_nt(_dev(bdescs), _dev(qdescs))
 
 
-def _before(sj, j, sp, p):
-    return (sj > sp) | ((sj == sp) & (j > p))
+def _mode_lists(groups, classic):
+    """[(positives, junk)] per mode, as the reference builds them (generic.py:150-170, 196-224)."""
+    if classic:
+        return [(groups['ok'], groups['junk'])]
+    return [(groups['easy'], groups['junk'] + groups['hard']),
+            (groups['easy'] + groups['hard'], groups['junk']),
+            (groups['hard'], groups['junk'] + groups['easy'])]
 
 
-def eval_aps_device(db, scores):
-    """scores: CUDA tensor [Q, N].  Returns the list the reference builds: one float per query
-    (classic protocol) or one {'easy','medium','hard'} dict per query."""
-    Q, N = scores.shape
-    assert Q == db.nquery and N == db.nimg, "scores should have shape (%d, %d)" % (db.nquery, db.nimg)
+def build_probe_tables(db):
+    """Host-side index tables for eval_aps_device, built once per dataset: the union list of listed
+    images per query (probe_idx [Q,P], -1 padded) and, per (query, mode), the positions of the mode's
+    positives and junk inside that list (CSR).  Duplicates are dropped; an image listed as positive AND
+    junk is junk (the reference writes junk last, generic.py:192)."""
+    Q = db.nquery
     classic = bool(db.relevants)
-    lists = []
+    modes = 1 if classic else 3
+    rows, pos_off, pos_list, junk_off, junk_list = [], [0], [], [0], []
     for q in range(Q):
         if classic:
             groups = {'ok': list(db.relevants[q]), 'junk': list(db.junk[q])}
         else:
             groups = {'easy': list(db.easy[q]), 'hard': list(db.hard[q]), 'junk': list(db.junk[q])}
-        lists.append(groups)
-    P = max(1, max(sum(len(v) for v in g.values()) for g in lists))
+        flat = list(dict.fromkeys(i for v in groups.values() for i in v))
+        where = {i: k for k, i in enumerate(flat)}
+        rows.append(flat)
+        for positives, junk in _mode_lists(groups, classic):
+            junkset = set(junk)
+            pos_list += [where[i] for i in dict.fromkeys(positives) if i not in junkset]
+            junk_list += [where[i] for i in sorted(junkset)]
+            pos_off.append(len(pos_list))
+            junk_off.append(len(junk_list))
+    P = max(1, max(len(r) for r in rows))
     probe = -np.ones((Q, P), dtype=np.int32)
-    for q, g in enumerate(lists):
-        flat = [i for v in g.values() for i in v]
-        probe[q, :len(flat)] = flat
-    out_counts = np.zeros((Q, P), dtype=np.int64)
-    out_scores = np.zeros((Q, P), dtype=np.float32)
-    for p0 in range(0, P, 1024):          # the kernel takes up to 1024 probes per query per launch
-        chunk = np.ascontiguousarray(probe[:, p0:p0 + 1024])
-        c, s = ops.rank_counts(scores.contiguous(), torch.from_numpy(chunk).cuda())
-        out_counts[:, p0:p0 + 1024] = c.cpu().numpy()
-        out_scores[:, p0:p0 + 1024] = s.cpu().numpy()
+    for q, r in enumerate(rows):
+        probe[q, :len(r)] = r
+    as_dev = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).cuda()   # noqa: E731
+    return dict(probe=torch.from_numpy(probe).cuda(), pos_off=as_dev(pos_off), pos_list=as_dev(pos_list or [0]),
+                junk_off=as_dev(junk_off), junk_list=as_dev(junk_list or [0]), modes=modes, classic=classic)
 
-    def ap(q, positives, junk):
-        """AP with `positives` relevant and `junk` removed; -1 when there is no positive."""
-        g = lists[q]
-        flat = [i for v in g.values() for i in v]
-        pos_of = {}
-        for k, i in enumerate(flat):
-            pos_of.setdefault(i, k)       # an index listed twice: any copy carries the same numbers
-        if not positives:
-            return -1
-        # an image listed as positive AND junk is junk (the reference writes junk last, generic.py:192)
-        junkset = set(junk)
-        pos = [i for i in dict.fromkeys(positives) if i not in junkset]
-        if not pos:
-            return -1
-        jk = np.array(sorted(junkset), dtype=np.int64)
-        js = out_scores[q, [pos_of[i] for i in jk]] if len(jk) else np.zeros(0, np.float32)
-        ranks = []
-        for i in pos:
-            k = pos_of[i]
-            n_before = int(out_counts[q, k])
-            if len(jk):
-                n_before -= int(np.sum(_before(js, jk, out_scores[q, k], i)))
-            ranks.append(n_before)
-        return compute_average_precision(np.sort(np.array(ranks)))
 
-    res = []
-    for q, g in enumerate(lists):
-        if classic:
-            a = ap(q, g['ok'], g['junk'])
-            res.append(0.0 if a == -1 else a)      # classic protocol has no -1 (generic.py:199-208)
-        else:
-            res.append({'easy': ap(q, g['easy'], g['junk'] + g['hard']),
-                        'medium': ap(q, g['easy'] + g['hard'], g['junk']),
-                        'hard': ap(q, g['hard'], g['junk'] + g['easy'])})
-    return res
+def eval_aps_device(db, scores, tables=None):
+    """scores: CUDA tensor [Q, N].  Returns the list the reference builds: one float per query
+    (classic protocol) or one {'easy','medium','hard'} dict per query.  Two kernels: the dense rank
+    counts of every listed image (dir_rank_counts, one pass over the score rows) and the junk-corrected
+    APs (dir_revisitop_ap); only Q x modes doubles come back to the host."""
+    Q, N = scores.shape
+    assert Q == db.nquery and N == db.nimg, "scores should have shape (%d, %d)" % (db.nquery, db.nimg)
+    t = tables if tables is not None else build_probe_tables(db)
+    counts, pscores = ops.rank_counts(scores.contiguous(), t['probe'])
+    ap = ops.revisitop_ap(t['probe'], counts, pscores, t['pos_off'], t['pos_list'], t['junk_off'],
+                          t['junk_list'], t['modes']).cpu().numpy()
+    if t['classic']:
+        return [0.0 if a == -1 else float(a) for a in ap[:, 0]]     # classic protocol has no -1 (generic.py:199-208)
+    return [{'easy': float(a[0]) if a[0] != -1 else -1, 'medium': float(a[1]) if a[1] != -1 else -1,
+             'hard': float(a[2]) if a[2] != -1 else -1} for a in ap]

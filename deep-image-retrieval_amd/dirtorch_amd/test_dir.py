@@ -32,21 +32,33 @@ from .utils.pytorch_loader import get_loader
 
 
 def expand_descriptors(descs, db=None, alpha=0, k=0):
-    """Replace each descriptor by the L2-normalised mean of itself and its k nearest neighbours in
-    `db` (or among the other rows of `descs`), each neighbour weighted by similarity**alpha."""
+    """alpha query expansion / database augmentation (test_dir.py:24-44): each descriptor becomes the
+    L2-normalised mean of itself and its k nearest neighbours in `db` (or among the OTHER rows of
+    `descs`), each neighbour weighted by similarity**alpha.  Similarity, top-k selection, weighted
+    mean and norm all run on the GPU (dir_expand_descriptors); ndarray in, ndarray out like the
+    reference.  Ties at the k-th similarity are broken by the larger index (np.argpartition leaves
+    them unspecified)."""
     assert k >= 0 and alpha >= 0, 'k and alpha must be non-negative'
     if k == 0:
         return descs
     descs = tonumpy(descs)
-    pool_ = descs if db is None else tonumpy(db)
-    sim = matmul(descs, pool_)                                   # fp32 MFMA similarity kernel
-    if db is None:
-        np.fill_diagonal(sim, 0)                                 # a row is not its own neighbour
-    k = int(k)
-    nn = np.argpartition(sim, -k, axis=1)[:, -k:]                # [n, k] neighbour indices
-    w = np.take_along_axis(sim, nn, axis=1) ** alpha             # [n, k]
-    mixed = (descs + np.einsum('nk,nkd->nd', w, pool_[nn])) / (k + 1)
-    return (mixed / np.linalg.norm(mixed, axis=1, keepdims=True)).astype(descs.dtype, copy=False)
+    pool_ = None if db is None else tonumpy(db)
+    m = len(descs) if pool_ is None else len(pool_)
+    if int(k) > m:
+        raise ValueError('kth(=%d) out of bounds (%d)' % (m - int(k), m))    # np.argpartition's error
+    from . import ops
+    out = ops.expand_descriptors(common._dev(descs), None if pool_ is None else common._dev(pool_),
+                                 alpha=float(alpha), k=int(k))
+    return out.cpu().numpy().astype(descs.dtype, copy=False)
+
+
+def _check_finite(feats, net):
+    """fp16 activations overflow at 65504: a checkpoint whose activations leave that range shows up
+    as inf/NaN descriptors.  One reduction + sync per extraction pass."""
+    if feats.numel() and not bool(torch.isfinite(feats).all()):
+        raise FloatingPointError('non-finite descriptors with compute dtype %s: activations left the 16-bit range; '
+                                 'run with DIRTORCH_AMD_DTYPE=bf16' % getattr(net, 'compute_dtype', '?'))
+    return feats
 
 
 def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=False, flip=None,
@@ -60,7 +72,7 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
     net.eval()
     if (not same_size and not ret_imgs and not flip and batch_size > 1 and net.iscuda
             and os.environ.get('DIRTORCH_AMD_BUCKET_BATCH', '1') != '0'):
-        return _extract_bucketed(loader, len(dataset), net, batch_size, desc)
+        return _check_finite(_extract_bucketed(loader, len(dataset), net, batch_size, desc), net)
     feats, kept = [], []
     nbatches = (len(dataset) + bs - 1) // bs
     with torch.no_grad():
@@ -75,7 +87,7 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
             feats.append(d.reshape(1, -1) if d.dim() == 1 else d)   # B == 1 comes back as [D]
             if ret_imgs:
                 kept.append(imgs.cpu() if ret_imgs == 'cpu' else imgs)
-    feats = torch.cat(feats, dim=0)
+    feats = _check_finite(torch.cat(feats, dim=0), net)
     if not ret_imgs:
         return feats
     return (torch.cat(kept, dim=0) if same_size else kept), feats
@@ -142,7 +154,7 @@ def extract_multiscale_features(dataset, scales, net, desc="Extract feats...", i
                 x = img if size == (W, H) else ops.resize_bilinear_u8(img, size)
                 per_scale.append(net(x).reshape(1, -1))
             rows.append(torch.cat(per_scale, dim=1))
-    return torch.cat(rows, dim=0)
+    return _check_finite(torch.cat(rows, dim=0), net)
 
 
 def extract_per_scale(dataset, trfs, net, desc, threads=8, batch_size=16, sharded=False):

@@ -174,9 +174,28 @@ def create(cmd_line, to_tensor=False, **vars):
                                   % (cmd_line, sorted(_ALLOWED)))
 
             def val(n):
-                if isinstance(n, ast.Name) and n.id in vars:   # mean / std / input_size
+                """Argument values: literals, the chain variables (mean / std / input_size),
+                PIL's `Image.<FILTER>` constants and + - * / // of numbers - the subset of the
+                reference's eval() that test-time chains use."""
+                if isinstance(n, ast.Name) and n.id in vars:
                     return vars[n.id]
-                return ast.literal_eval(n)
+                if (isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id == 'Image'
+                        and n.attr.isupper()):
+                    from PIL import Image
+                    if hasattr(Image, n.attr):
+                        return getattr(Image, n.attr)
+                if isinstance(n, ast.BinOp) and isinstance(n.op, (ast.Add, ast.Sub, ast.Mult, ast.Div, ast.FloorDiv)):
+                    a, b = val(n.left), val(n.right)
+                    if isinstance(a, (int, float)) and isinstance(b, (int, float)):
+                        if isinstance(n.op, (ast.Div, ast.FloorDiv)) and not b:
+                            raise SyntaxError("Cannot interpret this transform list: %s\nReason: division by zero" % cmd_line)
+                        return {ast.Add: lambda: a + b, ast.Sub: lambda: a - b, ast.Mult: lambda: a * b,
+                                ast.Div: lambda: a / b, ast.FloorDiv: lambda: a // b}[type(n.op)]()
+                try:
+                    return ast.literal_eval(n)
+                except (ValueError, TypeError, SyntaxError) as e:
+                    raise SyntaxError("Cannot interpret this transform list: %s\nReason: unsupported argument "
+                                      "(%s)" % (cmd_line, e))
             chain.append(_ALLOWED[node.func.id](*[val(a) for a in node.args],
                                                 **{k.arg: val(k.value) for k in node.keywords}))
     has_tensor = any(isinstance(t, ToTensor) for t in chain)

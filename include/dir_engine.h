@@ -198,7 +198,9 @@ int dir_upsample_add(const void* x, const void* low, void* y, int B, int H, int 
 int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream);
 /* K9/K11/K12: out[j][i] = alpha_i * (sum_k P[i][k] * (Q[j][k] - qsub[k])) + bias[i]
  *   P: [NP,K] fp32 (ldp), Q: [NQ,K] fp32 (ldq), out: [NQ,NP] fp32 (ldo); qsub/bias/alpha may be
- *   NULL.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Used as
+ *   NULL.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Any K >= 1 and any pitches ldp, ldq >= K (16-byte
+ *   loads when K, ldp, ldq are multiples of 4 and the bases 16-byte aligned, an element-wise gather
+ *   otherwise - e.g. --whitenv 50).  Used as
  *     FC          : P = fc.weight, Q = pooled features, bias = fc.bias   (rmac_resnet.py:66)
  *     PCA whiten  : P = components_[:v], Q = X, qsub = mean_, alpha = 1/(m*var^p) (common.py:221-232)
  *     similarity  : P = database descriptors, Q = queries -> scores[Q][N]       (common.py:30-38) */
@@ -230,9 +232,28 @@ int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mod
  * (dirtorch/datasets/generic.py:196-224).  For every query q and every probe p (a database index,
  * -1 = unused slot) counts[q][p] = number of database items that rank before it under
  * np.argsort(scores[q])[::-1]: score greater, or equal with a larger index.  probe_scores[q][p]
- * receives scores[q][probe].  scores: [Q][N] fp32 with row stride lds; P <= 1024. */
+ * receives scores[q][probe].  scores: [Q][N] fp32 with row stride lds; probe_idx / counts /
+ * probe_scores are [Q][P] (any P: the kernel takes 1024 probes per query per launch). */
 int dir_rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P,
                     int* counts, float* probe_scores, void* stream);
+/* N1, second half: the APs themselves on the device - ImageListRelevants.eval_query_AP
+ * (dirtorch/datasets/generic.py:196-224) + compute_average_precision (dirtorch/utils/evaluation.py:46-82)
+ * from the outputs of dir_rank_counts.  For every (query q, mode m < modes) the caller lists, as
+ * positions INTO row q of probe_idx, the positives pos_list[pos_off[q*modes+m] .. pos_off[q*modes+m+1])
+ * and the junk junk_list[junk_off[..] ..) of that mode (duplicates removed; an image that is both is
+ * junk - generic.py:192).  ap_out[q*modes+m] = the trapezoidal AP, summed in fp64 in the reference's
+ * order, or -1 when the mode has no positive.  terms: fp64 scratch, one slot per pos_list entry. */
+int dir_revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* probe_scores,
+                     const int* pos_off, const int* pos_list, const int* junk_off, const int* junk_list,
+                     int modes, double* terms, double* ap_out, void* stream);
+/* N3: alpha query expansion / database augmentation, expand_descriptors of
+ * dirtorch/test_dir.py:24-44.  out[i] = normalize(mean(descs[i], sim[i][j]^alpha * db[j] for the k
+ * rows j of db most similar to descs[i])), sim = descs . db^T in fp32; self_set != 0 (db == descs,
+ * m == n): a row is not its own neighbour (its self-similarity counts as 0, test_dir.py:33-34).
+ * descs [n][D], db [m][D], out [n][D] fp32 contiguous; sim: caller's scratch of sim_bytes >= 4*m
+ * (rows are processed in chunks of sim_bytes / (4*m)); 0 <= k <= min(m, 256), alpha >= 0. */
+int dir_expand_descriptors(const float* descs, int n, const float* db, int m, int D, int k, float alpha,
+                           int self_set, float* out, float* sim, size_t sim_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ PyTorch-CPU / NumPy, with no dependency on /root/reference at run time:
     pool                 dirtorch/utils/common.py:41-55
     whiten_features      dirtorch/utils/common.py:221-239
     matmul               dirtorch/utils/common.py:30-38
+    expand_descriptors   dirtorch/test_dir.py:24-44 (alpha-QE / DBA)
     compute_average_precision   dirtorch/utils/evaluation.py:46-82
     eval_query_AP        dirtorch/datasets/generic.py:189-224 (+ get_relevants/get_junk :150-170)
 
@@ -28,103 +29,21 @@ The third-party arithmetic underneath (PyTorch conv/BN/linear kernels, sklearn P
 `quant=` emulates the engine's 16-bit storage points (weights after BN folding, every activation
 tensor written to HBM) with fp32 accumulation, so kernel bugs can be told from precision drift.
 """
-import hashlib
 import math
-from collections import OrderedDict
+import os
+import sys
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
-ARCH = {
-    'resnet18': (False, [2, 2, 2, 2]),
-    'resnet50': (True, [3, 4, 6, 3]),
-    'resnet101': (True, [3, 4, 23, 3]),
-    'resnet152': (True, [3, 8, 36, 3]),
-}
-BN_EPS = 1e-5  # nn.BatchNorm2d default, resnet.py:117
-
-
-# ---- deterministic synthetic checkpoints ----------------------------------------------------
-def conv_specs(arch):
-    """[(weight key, bn prefix, cout, cin, k, stride)] in the reference's state-dict order."""
-    bottleneck, layers = ARCH[arch]
-    exp = 4 if bottleneck else 1
-    specs = [('conv1.weight', 'bn1', 64, 3, 7, 2)]
-    inplanes = 64
-    for s, planes in enumerate((64, 128, 256, 512)):
-        for j in range(layers[s]):
-            pre = 'layer%d.%d' % (s + 1, j)
-            stride = 2 if (j == 0 and s > 0) else 1
-            if bottleneck:
-                specs += [(pre + '.conv1.weight', pre + '.bn1', planes, inplanes, 1, 1),
-                          (pre + '.conv2.weight', pre + '.bn2', planes, planes, 3, stride),
-                          (pre + '.conv3.weight', pre + '.bn3', planes * 4, planes, 1, 1)]
-            else:
-                specs += [(pre + '.conv1.weight', pre + '.bn1', planes, inplanes, 3, stride),
-                          (pre + '.conv2.weight', pre + '.bn2', planes, planes, 3, 1)]
-            if j == 0 and (stride != 1 or inplanes != planes * exp):
-                specs.append((pre + '.downsample.0.weight', pre + '.downsample.1', planes * exp,
-                              inplanes, 1, stride))
-            inplanes = planes * exp
-    return specs, inplanes
-
-
-def _rng(seed, key):
-    h = hashlib.sha256(('%d:%s' % (seed, key)).encode()).digest()
-    return np.random.RandomState(int.from_bytes(h[:4], 'little'))
-
-
-def synth_state_dict(arch, seed=0, out_dim=2048, gemp=2.7, pooling='gem', head='rmac'):
-    """Deterministic per-key weights: identical wherever they are generated (golden script, tests,
-    GPU box).  He-normal convs as reset_weights (resnet.py:92-99) but NON-trivial BatchNorm
-    statistics, a non-integer GeM exponent, and a damped last BN per block so that activations
-    stay O(1..100) through 33 residual blocks (fp16-safe)."""
-    specs, feat = conv_specs(arch)
-    sd = OrderedDict()
-    for wkey, bn, cout, cin, k, _ in specs:
-        n = k * k * cout
-        sd[wkey] = torch.from_numpy(
-            (_rng(seed, wkey).standard_normal((cout, cin, k, k)) * math.sqrt(2. / n)).astype(np.float32))
-        r = _rng(seed, bn)
-        last = bn.endswith('bn3') or (not ARCH[arch][0] and bn.endswith('bn2')) or 'downsample' in bn
-        lo, hi = (0.25, 0.5) if last else (0.6, 1.2)
-        sd[bn + '.weight'] = torch.from_numpy(r.uniform(lo, hi, cout).astype(np.float32))
-        sd[bn + '.bias'] = torch.from_numpy((r.standard_normal(cout) * 0.1).astype(np.float32))
-        sd[bn + '.running_mean'] = torch.from_numpy((r.standard_normal(cout) * 0.1).astype(np.float32))
-        sd[bn + '.running_var'] = torch.from_numpy(r.uniform(0.6, 1.6, cout).astype(np.float32))
-        sd[bn + '.num_batches_tracked'] = torch.tensor(1, dtype=torch.long)
-    if head in ('fpn', 'fpn0'):   # rmac_resnet_fpn.py:24-46 (state-dict order of the module)
-        dim1, dim2 = feat // 2, feat
-        if head == 'fpn':
-            for key, shape in (('conv1x5.weight', (dim1, dim2, 1, 1)), ('conv3c4.weight', (dim1, dim1, 3, 3))):
-                n = shape[2] * shape[3] * shape[0]
-                sd[key] = torch.from_numpy(
-                    (_rng(seed, key).standard_normal(shape) * math.sqrt(2. / n)).astype(np.float32))
-        sd['adpoolx5.p'] = torch.ones(1) * gemp
-        sd['adpoolc4.p'] = torch.ones(1) * (gemp + 0.4)
-        feat = dim1 + dim2
-    elif head == 'rmac' and pooling.startswith('gem'):
-        sd['adpool.p'] = torch.ones(1) * gemp
-    r = _rng(seed, 'fc')
-    bound = 1. / math.sqrt(feat)
-    sd['fc.weight'] = torch.from_numpy(r.uniform(-bound, bound, (out_dim, feat)).astype(np.float32))
-    sd['fc.bias'] = torch.from_numpy(r.uniform(-bound, bound, out_dim).astype(np.float32))
-    return sd
-
-
-def synth_images(seed, B, H, W):
-    """Normalised fp32 NCHW images with planted low-frequency structure (not white noise)."""
-    r = _rng(seed, 'img%dx%dx%d' % (B, H, W))
-    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing='ij')
-    imgs = np.empty((B, 3, H, W), np.float32)
-    for b in range(B):
-        for c in range(3):
-            f = r.uniform(1, 6, 2)
-            ph = r.uniform(0, 6.28, 2)
-            imgs[b, c] = (np.sin(f[0] * 6.28 * yy + ph[0]) * np.cos(f[1] * 6.28 * xx + ph[1])
-                          + 0.35 * r.standard_normal((H, W)))
-    return torch.from_numpy(imgs)
+# Input generators (deterministic synthetic checkpoints / images) live in tests/synth.py: they are not
+# part of the checker.  Re-exported here because the tests address them as O.synth_*.
+_TESTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests')
+if _TESTS not in sys.path:
+    sys.path.insert(0, _TESTS)
+from synth import (ARCH, BN_EPS, conv_specs, synth_state_dict, synth_images,  # noqa: E402,F401
+                   calibrated_state_dict)
 
 
 # ---- 16-bit emulation ---------------------------------------------------------------------------
@@ -364,6 +283,28 @@ def whiten_features(X, pca, l2norm=True, whitenp=0.5, whitenv=None, whitenm=1.0)
 def matmul(A, B):
     """Q x N similarity scores as fp32 NumPy (common.matmul)."""
     return np.dot(np.asarray(A), np.asarray(B).T)
+
+
+def expand_descriptors(descs, db=None, alpha=0, k=0):
+    """alpha query expansion / database augmentation (test_dir.py:24-44): mean of a descriptor and its
+    k most similar rows of `db` (weights sim**alpha), L2-normalised; db=None expands the set against
+    itself with the diagonal of the similarity zeroed."""
+    assert k >= 0 and alpha >= 0
+    if k == 0:
+        return descs
+    descs = np.asarray(descs)
+    n = descs.shape[0]
+    db_descs = np.asarray(db) if db is not None else descs
+    sim = matmul(descs, db_descs)
+    if db is None:
+        sim[np.diag_indices(n)] = 0
+    idx = np.argpartition(sim, int(-k), axis=1)[:, int(-k):]
+    out = np.zeros_like(descs)
+    for i in range(n):
+        rows = np.vstack([descs[i]] + [db_descs[j, :] * sim[i, j] ** alpha for j in idx[i]])
+        new_q = np.mean(rows, axis=0)
+        out[i] = new_q / np.linalg.norm(new_q)
+    return out
 
 
 # ---- ranking / AP (revisited Oxford/Paris protocol) ---------------------------------------------------

@@ -3,8 +3,18 @@
 
     python scripts/summarize_prof.py stats  <dir> <out.txt>     # --kernel-trace --stats run
     python scripts/summarize_prof.py pmc    <fetch_dir> <write_dir> <out.json> [<traffic.json>]
+    python scripts/summarize_prof.py table  <launches.json> <stats_dir> <sq_dir> <fetch_dir> <write_dir> \
+                                            <out.txt> [<traffic.json>]
 
 stats: per-kernel calls / total / average duration from *kernel_trace.csv (or *kernel_stats.csv).
+table: the per-kernel ROOFLINE table.  launches.json (bench.py --dump-launches) is the launch
+       sequence of one forward with algorithmic flops / bytes per launch; rocprofv3 dispatches of the
+       engine's kernels are aligned with it by position (every forward issues the same sequence), so
+       each (kernel, layer shape) group gets its own duration, HBM traffic and MFMA-busy figures:
+         MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCCs * 256 CUs * 4 SIMDs)   (busy
+         cycles are summed over all SIMDs, 32 per 32x32x16 MFMA; GRBM_GUI_ACTIVE is summed over the
+         8 XCCs - both checked against SQ_INSTS_MFMA and the kernel duration), clock = GUI_ACTIVE per
+         XCC / duration.
 pmc:   per-kernel mean FETCH_SIZE / WRITE_SIZE per dispatch -> HBM bytes per launch.  gfx950
        corrections from /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
        FETCH_SIZE reads exactly half of a wide coalesced stream, so it is doubled; WRITE_SIZE is
@@ -97,8 +107,120 @@ def pmc(fd, wd, out, traffic=None):
                                                               v['hbm_write_bytes_per_launch'] / 1e6))
 
 
+# ---- per-kernel roofline table ---------------------------------------------------------------------
+ENGINE_PREFIX = ('conv_igemm<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
+PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
+
+
+def bench_kernel_name(k):
+    """rocprof short name -> the name bench.py's profile records carry."""
+    k = re.sub(r'(/stem)?\[\w+\]$', '', k)
+    return {'stem_pool_kernel': 'stem_pool', 'prep_input_kernel': 'prep_input', 'global_pool_kernel': 'global_pool',
+            'gemm_nt_small_kernel': 'gemm_nt_f32', 'gemm_nt_f32_kernel': 'gemm_nt_f32',
+            'maxpool_kernel': 'maxpool_3x3s2', 'upsample_add_kernel': 'upsample_add'}.get(k, k)
+
+
+def layer_group(name):
+    parts = name.split('.')
+    return parts[0] + '.' + parts[2] if len(parts) == 3 and parts[0].startswith('layer') else name
+
+
+def aligned(d, seq, counters=None):
+    """[(launch index in seq, duration ns, {counter: value})] for every engine dispatch of database d."""
+    con = db(d)
+    rows = []
+    for disp, name, dur in con.execute('select dispatch_id, name, duration from kernels order by dispatch_id'):
+        k = bench_kernel_name(short(name))
+        if k.startswith(ENGINE_PREFIX):
+            rows.append((disp, k, dur))
+    vals = defaultdict(dict)
+    if counters:
+        for disp, cn, v in con.execute('select dispatch_id, counter_name, counter_value from pmc_events'):
+            vals[disp][cn] = vals[disp].get(cn, 0.0) + float(v)    # per-XCC / per-SE instances: summed
+    out, pos = [], 0
+    L = len(seq)
+    for disp, k, dur in rows:
+        want = seq[pos % L]['kernel']
+        if k != want:
+            # tolerate kernels outside the recorded sequence (e.g. a warm-up autotune); resync on the head
+            if k == seq[0]['kernel']:
+                pos = (pos // L + 1) * L if pos % L else pos
+            else:
+                continue
+        out.append((pos % L, dur, vals.get(disp, {})))
+        pos += 1
+    return out
+
+
+def table(launches, stats_d, sq_d, fetch_d, write_d, out, traffic=None):
+    seq = json.load(open(launches))
+    groups = defaultdict(lambda: defaultdict(float))
+
+    def key(i):
+        r = seq[i]
+        return (r['kernel'], layer_group(r['name']), r['flops'], r['bytes'])
+
+    for i, dur, _ in aligned(stats_d, seq):
+        g = groups[key(i)]
+        g['n'] += 1
+        g['us'] += dur / 1e3
+    for d in (sq_d, fetch_d, write_d):
+        if not d or not os.path.isdir(d):
+            continue
+        tag = os.path.basename(d.rstrip('/'))
+        for i, dur, v in aligned(d, seq, True):
+            g = groups[key(i)]
+            g['n_' + tag] += 1
+            g['us_' + tag] += dur / 1e3
+            for cn, x in v.items():
+                g[cn] += x
+                g['n_' + cn] += 1
+    nstep = max(1, min(int(g['n']) for g in groups.values() if g['n']))
+    tot_us = sum(g['us'] for g in groups.values())
+    tot_fl = sum(k[2] * g['n'] for k, g in groups.items())
+    lines = ['# per-kernel roofline table: rocprofv3 --kernel-trace durations + --pmc passes aligned with bench.py\'s',
+             '# launch sequence (scripts/summarize_prof.py table).  bound: AI vs 2.5 PF / 8 TB/s = 312 FLOP/B;',
+             '# frac = achieved / that roof; traffic = PMC HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB) / algorithmic bytes;',
+             '# MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); clk = GRBM_GUI_ACTIVE/8 / duration.',
+             '%-34s %-20s %5s %8s %6s %9s %9s %8s %8s %5s %6s %8s %8s %6s' % (
+                 'kernel', 'layers', 'n/st', 'avg_us', 'share', 'GFLOP', 'MB', 'TF/s', 'GB/s', 'bound', 'frac',
+                 'traffic', 'MfmaUtil', 'clkGHz')]
+    tr = defaultdict(dict)
+    for k, g in sorted(groups.items(), key=lambda kv: -kv[1]['us']):
+        kern, grp, fl, by = k
+        if not g['n']:
+            continue
+        us = g['us'] / g['n']
+        tf = fl / us / 1e6 if fl else 0.0
+        gbs = by / us / 1e3 if by else 0.0
+        hbm = (fl / by) < (PEAK_TF * 1e12) / (PEAK_GBS * 1e9) if (fl and by) else True
+        frac = gbs / PEAK_GBS if hbm else tf / PEAK_TF
+        traffic_b = None
+        if g['n_FETCH_SIZE'] and g['n_WRITE_SIZE']:
+            traffic_b = (2 * g['FETCH_SIZE'] / g['n_FETCH_SIZE'] + g['WRITE_SIZE'] / g['n_WRITE_SIZE']) * 1024
+            tr[kern][grp] = traffic_b
+        mfma = clk = None
+        if g['n_GRBM_GUI_ACTIVE'] and g['n_SQ_VALU_MFMA_BUSY_CYCLES']:
+            gui = g['GRBM_GUI_ACTIVE'] / g['n_GRBM_GUI_ACTIVE'] / NXCC
+            mfma = g['SQ_VALU_MFMA_BUSY_CYCLES'] / g['n_SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * NSIMD)
+            tagus = g['us_' + os.path.basename(sq_d.rstrip('/'))] / max(1, g['n_' + os.path.basename(sq_d.rstrip('/'))])
+            clk = gui / (tagus * 1e3)
+        lines.append('%-34s %-20s %5.1f %8.1f %6.3f %9.2f %9.1f %8.1f %8.1f %5s %6.3f %8s %8s %6s' % (
+            kern, grp, g['n'] / nstep, us, g['us'] / tot_us, fl / 1e9, by / 1e6, tf, gbs, 'hbm' if hbm else 'mfma', frac,
+            '%.2fx' % (traffic_b / by) if traffic_b and by else '-', '%.3f' % mfma if mfma is not None else '-',
+            '%.2f' % clk if clk is not None else '-'))
+    lines.append('# step: %.1f us of engine kernels per forward, %.1f TFLOP/s = %.3f of the 2.5 PF dense MFMA peak' % (
+        tot_us / nstep, tot_fl / tot_us / 1e6, tot_fl / tot_us / 1e6 / PEAK_TF))
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+    if traffic:
+        json.dump(tr, open(traffic, 'w'), indent=1)
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'table':
+        table(*sys.argv[2:])
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(*sys.argv[2:])

@@ -37,3 +37,9 @@ def head_goldens():
 def label_goldens():
     import numpy as np
     return np.load(os.path.join(GOLDEN, 'label_goldens.npz'))
+
+
+@pytest.fixture(scope='session')
+def qe_goldens():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, 'qe_goldens.npz'))

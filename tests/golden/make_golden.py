@@ -2,7 +2,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py [model] [head] [postproc] [label]
+    PYTHONPATH=/root/reference DB_ROOT=/tmp python tests/golden/make_golden.py [model] [head] [postproc] [label] [qe]
 
 What is pinned (reference file:line):
     descriptors      dirtorch.nets.create_model(...)(x)      nets/__init__.py:24, rmac_resnet.py:39-69
@@ -16,8 +16,8 @@ What is pinned (reference file:line):
     label AP / top-k Dataset.eval_query_AP / eval_query_top  datasets/dataset.py:71-105 (ImageListLabels[Q])
     accuracy_topk, compute_average_precision_quantized       utils/evaluation.py:8-38,85-98
 
-Weights and images come from oracle/dir_oracle.py's deterministic generators (synth_state_dict,
-synth_images), so the fixtures hold only the reference's OUTPUTS (a few hundred KB).
+Weights, images and descriptors come from the deterministic generators of tests/synth.py
+(synth_state_dict, synth_images, synth_descriptors; re-exported by oracle/dir_oracle.py), so the fixtures hold only the reference's OUTPUTS (a few hundred KB).
 """
 import os
 import pickle
@@ -30,6 +30,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ.setdefault('DB_ROOT', tempfile.gettempdir())
 sys.path.insert(0, '/root/reference')
 
@@ -201,8 +202,30 @@ def postproc_goldens():
     print('postproc goldens written')
 
 
+# (k, alpha) pairs of the alpha-QE / DBA goldens; mirrored by tests (QE_CASES)
+QE_CASES = [(1, 0), (1, 3), (5, 0), (5, 3), (3, 1)]
+
+
+def qe_goldens():
+    """alpha query expansion / database augmentation: expand_descriptors (test_dir.py:24-44), the
+    self-set form (--adba: db=None, diagonal zeroed) and the db= form (--aqe)."""
+    from dirtorch.test_dir import expand_descriptors as ref_expand
+    import synth
+    q = synth.synth_descriptors(31, 12, 64)
+    db = synth.synth_descriptors(32, 40, 64)
+    out = {}
+    for k, alpha in QE_CASES:
+        out['qe.self.k%d.a%d' % (k, alpha)] = ref_expand(db.copy(), alpha=alpha, k=k)
+        out['qe.db.k%d.a%d' % (k, alpha)] = ref_expand(q.copy(), db=db.copy(), alpha=alpha, k=k)
+    assert ref_expand(q, db=db, alpha=3, k=0) is q           # k == 0: the input object itself
+    np.savez_compressed(os.path.join(HERE, 'qe_goldens.npz'), **out)
+    print('qe goldens written', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'head', 'postproc', 'label']
+    which = sys.argv[1:] or ['model', 'head', 'postproc', 'label', 'qe']
+    if 'qe' in which:
+        qe_goldens()
     if 'model' in which:
         model_goldens()
     if 'head' in which:

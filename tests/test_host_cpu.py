@@ -99,6 +99,31 @@ def test_transform_dsl():
         T.create('RandomCrop(8)', **pre)
     with pytest.raises(SyntaxError):
         T.create('__import__("os").system("true")', **pre)
+    # chains the reference's eval() accepts: PIL filter constants and simple arithmetic
+    sc = T.create('Scale(2*16, interpolation=Image.BICUBIC)', to_tensor='uint8', **pre)
+    assert sc.transforms[0].interpolation == Image.BICUBIC and sc(img).shape == (32, 43, 3)
+    assert T.create('Scale(input_size//2)', to_tensor='uint8', **pre)(img).shape == (112, 149, 3)
+    with pytest.raises(SyntaxError):       # an unsupported argument is the same SyntaxError, not a bare ValueError
+        T.create('Scale(open("/etc/passwd"))', **pre)
+    with pytest.raises(SyntaxError):
+        T.create('Scale(Image.__class__)', **pre)
+
+
+def test_small_helpers_follow_the_reference(tmp_path):
+    """mkdir's isfile='auto' (convenient.py:11-23) and delete_fc leaving the caller's dict alone
+    (nets/__init__.py:67-95: the reference deletes from a local copy)."""
+    import synth
+    from dirtorch_amd import nets
+    from dirtorch_amd.utils.convenient import mkdir
+    mkdir(str(tmp_path / 'a' / 'b' / 'out.json'))            # has an extension: a file path
+    assert (tmp_path / 'a' / 'b').is_dir() and not (tmp_path / 'a' / 'b' / 'out.json').exists()
+    mkdir(str(tmp_path / 'c' / 'd'))                         # no extension: a directory
+    assert (tmp_path / 'c' / 'd').is_dir()
+    sd = synth.synth_state_dict('resnet18', seed=1, out_dim=64)
+    net = nets.create_model('resnet18_rmac', pretrained='', out_dim=64)
+    keys = list(sd.keys())
+    nets.load_pretrained_weights(net, sd, delete_fc=True)
+    assert list(sd.keys()) == keys and 'fc.weight' in sd
 
 
 def test_loader_batches_even_single_threaded(tmp_path):

@@ -184,3 +184,23 @@ def test_eval_query_ap(postproc_goldens):
     assert g['evalap.easy'][4] == -1
     m = O.mean_ap(scores, gnd)
     assert m['mAP-easy'] == pytest.approx(np.mean([v for v in g['evalap.easy'] if v >= 0]))
+
+
+# mirrors QE_CASES of tests/golden/make_golden.py
+QE_CASES = [(1, 0), (1, 3), (5, 0), (5, 3), (3, 1)]
+
+
+def qe_inputs():
+    import synth
+    return synth.synth_descriptors(31, 12, 64), synth.synth_descriptors(32, 40, 64)
+
+
+@pytest.mark.parametrize('k,alpha', QE_CASES)
+def test_expand_descriptors_matches_reference(k, alpha, qe_goldens):
+    """alpha-QE (db=) and DBA (self-set) of the oracle against the reference's expand_descriptors."""
+    q, db = qe_inputs()
+    got_self = O.expand_descriptors(db.copy(), alpha=alpha, k=k)
+    got_db = O.expand_descriptors(q.copy(), db=db.copy(), alpha=alpha, k=k)
+    np.testing.assert_allclose(got_self, qe_goldens['qe.self.k%d.a%d' % (k, alpha)], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got_db, qe_goldens['qe.db.k%d.a%d' % (k, alpha)], rtol=0, atol=1e-6)
+    assert O.expand_descriptors(q, db=db, alpha=alpha, k=0) is q

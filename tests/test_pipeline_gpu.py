@@ -22,8 +22,10 @@ def save_images(root, names, sizes, seed):
         Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(os.path.join(root, name))
 
 
-def oracle_descriptors(sd, arch, files, rois=None):
-    """What the reference computes per image: PIL RGB (-> crop) -> ToTensor -> Normalize -> net."""
+def oracle_descriptors(sd, arch, files, rois=None, quant=None):
+    """What the reference computes per image: PIL RGB (-> crop) -> ToTensor -> Normalize -> net.
+    quant='bf16'|'fp16': the same with the engine's 16-bit storage points emulated (an IDEAL 16-bit
+    implementation; used to derive what a dtype can lose, never as the thing compared against)."""
     import dir_oracle as O
     from PIL import Image
     mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
@@ -34,7 +36,7 @@ def oracle_descriptors(sd, arch, files, rois=None):
         if rois is not None:
             img = img.crop(rois[i])
         x = (torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255 - mean) / std
-        out.append(O.rmac_forward(sd, arch, x[None]).reshape(1, -1))
+        out.append(O.rmac_forward(sd, arch, x[None], quant=quant).reshape(1, -1))
     return torch.cat(out, 0)
 
 
@@ -83,13 +85,14 @@ def test_extract_features_cli(tmp_path):
     assert raw.shape == (5, 2048) and np.all(1 - O.cosine(raw, ref) < 1e-4)
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp16', 1e-3), ('bf16', 1e-2)])
-def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch, dtype, tol):
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
+def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch, dtype):
     """python -m dirtorch_amd.test_dir --dataset ROxford5K on a synthetic revisitop-format dataset
-    (files, ROI crops, pickled PCA, JSON output).  With 14 images one rank flip between two
-    near-tied scores moves a mode's mAP by ~2e-3, so the 0.1-point gate (1e-3) is applied in fp16
-    (score noise 1.7e-3) and the bf16 run (score noise 1.7e-2 after whitening) gets 1 point here;
-    the statistically meaningful bf16 gate is test_extract_whiten_rank_map_parity below."""
+    (files, ROI crops, pickled PCA, JSON output).  Gate: 0.1 mAP point (1e-3, north-star) in fp16.
+    bf16 carries 8x the rounding noise; its allowance is DERIVED, per mode, from what an ideal
+    bf16-storage implementation loses on the same data (the oracle's quant= emulation): 1e-3 + 3 x
+    |mAP_emulated - mAP_fp32| - with 14 images one rank flip between near-tied scores moves a mode's mAP
+    by ~2e-3, so the emulation itself is off the fp32 value by that order."""
     import dir_oracle as O
     from dirtorch_amd import test_dir as td
     monkeypatch.setenv('DIRTORCH_AMD_DTYPE', dtype)
@@ -99,8 +102,7 @@ def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch, dtype, tol):
     names = ['im%02d' % i for i in range(N)]
     sizes = [(int(r.randint(70, 130)), int(r.randint(70, 130))) for _ in range(N)]
     save_images(str(root / 'jpg'), [n + '.jpg' for n in names], sizes, 2)
-    # planted structure (random-weight descriptors of unrelated images are ~0.9996 cosine apart, the
-    # same order as 16-bit noise - SURVEY.md §7): positives are noisy copies of the query image
+    # planted structure: positives are noisy copies of the query image
     from PIL import Image
     gnd = []
     for q in range(Q):
@@ -118,8 +120,9 @@ def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch, dtype, tol):
     monkeypatch.setenv('DB_ROOT', str(tmp_path))
     sd = O.synth_state_dict('resnet18', seed=7, gemp=3.0)
     files = [str(root / 'jpg' / (n + '.jpg')) for n in names]
+    rois = [tuple(g['bbx']) for g in gnd]
     bd = oracle_descriptors(sd, 'resnet18', files).numpy()
-    qd = oracle_descriptors(sd, 'resnet18', files[:Q], [tuple(g['bbx']) for g in gnd]).numpy()
+    qd = oracle_descriptors(sd, 'resnet18', files[:Q], rois).numpy()
     # whitening learned on the descriptor distribution itself (as Landmarks_clean is for the real
     # models): a PCA unrelated to the data would turn the ranking into noise amplification
     from sklearn.decomposition import PCA
@@ -130,25 +133,40 @@ def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch, dtype, tol):
     res = td.main(['--dataset', 'ROxford5K', '--checkpoint', ck, '--gpu', '0', '--threads', '2',
                    '--whiten', 'Landmarks_clean', '--whitenp', '0.25', '--out-json', js, '--detailed'])
     P = O.PCAParams(pca.mean_, pca.components_, pca.explained_variance_, True)
-    scores = O.matmul(O.whiten_features(qd, P, whitenp=0.25), O.whiten_features(bd, P, whitenp=0.25))
-    ref = O.mean_ap(scores, gnd)
+
+    def protocol_map(b, q):
+        return O.mean_ap(O.matmul(O.whiten_features(q, P, whitenp=0.25), O.whiten_features(b, P, whitenp=0.25)), gnd)
+
+    ref = protocol_map(bd, qd)
+    tol = {k: 1e-3 for k in ref}
+    if dtype == 'bf16':
+        emu = protocol_map(oracle_descriptors(sd, 'resnet18', files, quant='bf16').numpy(),
+                           oracle_descriptors(sd, 'resnet18', files[:Q], rois, quant='bf16').numpy())
+        tol = {k: 1e-3 + 3 * abs(emu[k] - ref[k]) for k in ref}
     for k in ('mAP-easy', 'mAP-medium', 'mAP-hard'):
-        assert abs(res[k] - ref[k]) < tol, (k, res[k], ref[k])
+        print('\n[pipeline-cli] %s %s: engine %.5f oracle %.5f allowance %.2e' % (dtype, k, res[k], ref[k], tol[k]))
+        assert abs(res[k] - ref[k]) <= tol[k], (k, res[k], ref[k], tol[k])
     assert len(res['APs-medium']) == Q and os.path.isfile(js)
 
 
-@pytest.mark.parametrize('dtype,tol_w,tol_map', [('fp16', 5e-4, 1e-3), ('bf16', 2e-2, 1e-2)])
-def test_extract_whiten_rank_map_parity(dtype, tol_w, tol_map):
+@pytest.mark.parametrize('ckpt', ['synthetic', 'calibrated'])
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
+def test_extract_whiten_rank_map_parity(dtype, ckpt):
     """extraction -> PCA whitening -> similarity -> revisitop mAP on 400 images / 25 queries with
-    planted near-duplicates.
+    planted near-duplicates, on two checkpoints:
 
-    Descriptors (pre-whitening) must be within 1e-4 cosine of the oracle in both dtypes (measured
-    ~1e-6).  After whitening the gate depends on the data: a random-weight ResNet is rank-collapsed
-    (unrelated images have descriptor cosine 0.9998, total variance 3e-4), so mean subtraction +
-    1/sigma^0.25 rescaling amplifies the 16-bit rounding noise of the trunk by ~70x (oracle-only
-    emulation: bf16 7e-3 whitened 1-cos / 1e-3 mAP, fp16 1.4e-4 / 1e-4).  With that amplification the
-    north-star gates (1e-4 cosine, 0.1 mAP point) are met in fp16; bf16 gets the emulation-derived
-    bound here.  Trained checkpoints are not rank-collapsed (none is available)."""
+      synthetic   random He-init weights: descriptors of unrelated images are collinear (cosine 0.9998),
+                  so whitening (mean subtraction + 1/sigma^0.25) amplifies trunk rounding noise ~70x;
+      calibrated  the same weights with BatchNorm statistics calibrated on synthetic images
+                  (tests/synth.py): unrelated descriptors have cosine ~0.8, the regime of a trained net.
+
+    Gates.  fp16: the north-star tolerances as stated - descriptors and whitened descriptors within
+    1e-4 cosine, mAP within 0.1 point (1e-3) - on the calibrated checkpoint; on the collinear one the
+    whitened gate is what an ideal fp16 implementation achieves there (emulation-derived, as below).
+    bf16: no fixed number is honest - an IDEAL bf16-storage implementation (the oracle's quant=
+    emulation of the engine's storage points) is itself 2e-4 / 1e-3 away on the calibrated checkpoint -
+    so every bf16 allowance is 3 x the emulation's own distance from fp32, computed here on the same
+    data, and the engine must also sit within that distance OF the emulation."""
     import dir_oracle as O
     from dirtorch_amd import nets
     from dirtorch_amd.utils import common
@@ -163,26 +181,48 @@ def test_extract_whiten_rank_map_parity(dtype, tol_w, tol_map):
         gnd.append({'easy': sorted(idx[:4].tolist()), 'hard': sorted(idx[4:8].tolist()),
                     'junk': sorted([q] + idx[8:].tolist())})
     x = torch.from_numpy(imgs)
-    sd = O.synth_state_dict('resnet18', seed=7)
-    ref = torch.cat([O.rmac_forward(sd, 'resnet18', x[i:i + 50]) for i in range(0, N, 50)]).numpy()
+    if ckpt == 'synthetic':
+        sd = O.synth_state_dict('resnet18', seed=7)
+    else:
+        sd = O.calibrated_state_dict('resnet18', O.synth_images(99, 32, S, S), seed=7)
+
+    def oracle(quant=None):
+        return torch.cat([O.rmac_forward(sd, 'resnet18', x[i:i + 50], quant=quant) for i in range(0, N, 50)]).numpy()
+
+    ref, emu = oracle(), oracle(dtype)
     net = nets.create_model('resnet18_rmac', pretrained='')
     net.load_state_dict(sd)
     net.compute_dtype = dtype
     net.cuda()
     got = torch.cat([net(x[i:i + 50].cuda()) for i in range(0, N, 50)]).cpu().numpy()
-    assert np.all(1 - O.cosine(got, ref) < 1e-4), (1 - O.cosine(got, ref)).max()
+    pair = ref[Q:Q + 100] @ ref[Q + 100:Q + 200].T
+    if ckpt == 'calibrated':
+        assert pair.mean() < 0.9, pair.mean()               # the checkpoint is not rank-collapsed
     P = O.fit_pca(ref[Q:])
     kw = dict(whitenp=0.25, whitenv=16)
-    ref_w = O.whiten_features(ref, P, **kw)
+    ref_w, emu_w = O.whiten_features(ref, P, **kw), O.whiten_features(emu, P, **kw)
     got_w = common.whiten_features(got, P, **kw)
-    assert np.all(1 - O.cosine(got_w, ref_w) < tol_w), (1 - O.cosine(got_w, ref_w)).max()
     # the whitening kernel itself adds nothing: same input, device vs oracle
-    same_in = common.whiten_features(ref, P, **kw)
-    assert np.all(1 - O.cosine(same_in, ref_w) < 1e-6)
+    assert np.all(1 - O.cosine(common.whiten_features(ref, P, **kw), ref_w) < 1e-6)
+    e_raw, e_w = (1 - O.cosine(got, ref)).max(), (1 - O.cosine(got_w, ref_w)).max()
+    i_raw, i_w = (1 - O.cosine(emu, ref)).max(), (1 - O.cosine(emu_w, ref_w)).max()
     m_ref = O.mean_ap(O.matmul(ref_w[:Q], ref_w), gnd)
+    m_emu = O.mean_ap(O.matmul(emu_w[:Q], emu_w), gnd)
     m_got = O.mean_ap(common.matmul(got_w[:Q], got_w), gnd)
-    for k in m_ref:
-        assert abs(m_ref[k] - m_got[k]) < tol_map, (k, m_ref[k], m_got[k])
+    d_map = max(abs(m_ref[k] - m_got[k]) for k in m_ref)
+    i_map = max(abs(m_ref[k] - m_emu[k]) for k in m_ref)
+    print('\n[pipeline] %s %s: mean cosine of unrelated images %.4f | 1-cos raw: engine %.2e ideal-16bit %.2e | '
+          'whitened: engine %.2e ideal %.2e | max |dmAP|: engine %.2e ideal %.2e | mAP-medium %.3f'
+          % (ckpt, dtype, pair.mean(), e_raw, i_raw, e_w, i_w, d_map, i_map, m_ref['mAP-medium']))
+    if dtype == 'fp16' and ckpt == 'calibrated':            # the north-star numbers, as stated
+        assert e_raw < 1e-4 and e_w < 1e-4 and d_map < 1e-3, (e_raw, e_w, d_map)
+    else:
+        assert e_raw < max(1e-4, 3 * i_raw), (e_raw, i_raw)
+        assert e_w < max(1e-4, 3 * i_w), (e_w, i_w)
+        assert d_map < 1e-3 + 3 * i_map, (d_map, i_map)
+    # and the engine is an implementation OF that 16-bit arithmetic: as close to the emulation as the
+    # emulation is to fp32
+    assert (1 - O.cosine(got, emu)).max() < max(1e-5, 4 * i_raw)   # two independent roundings add: ~2x
     assert m_ref['mAP-easy'] > 0.5        # the planted structure is actually retrievable
 
 

@@ -72,24 +72,34 @@ def test_device_ap_equals_host_protocol(tmp_path, classic):
 
 
 def test_million_distractors_ranking(tmp_path):
-    """BASELINE config D scale on one GPU: 70 queries x (6322 + 1e6 distractors), D = 128 here to
-    keep the CPU cross-check cheap.  Properties: device AP == host AP on the same device scores for
-    sampled queries; adding distractors can only lower AP."""
+    """BASELINE config D on one GPU at its real dimensions: 70 queries x (6322 + 1e6 distractors) x
+    2048-d fp32 descriptors (8.2 GB, generated on the device).  Checks: the similarity kernel against
+    fp64 dot products of sampled entries; device AP == host protocol (ImageListRelevants.eval_query_AP
+    over the downloaded row) for sampled queries; planted positives are actually retrieved."""
     from dirtorch_amd import ranking
     r = np.random.RandomState(2)
-    Nb, Nd, Q, D = 6322, 1000000, 70, 128
-    db, gnd = make_db(tmp_path, Nb + Nd, Q, r, npos=40, njunk=10)
+    Nb, Nd, Q, D = 6322, 1000000, 70, 2048
+    N = Nb + Nd
+    db, gnd = make_db(tmp_path, N, Q, r, npos=40, njunk=10)
     g = torch.Generator(device='cuda').manual_seed(3)
-    base = torch.randn(Nb + Nd, D, generator=g, device='cuda')
+    base = torch.empty(N, D, device='cuda')
+    for i in range(0, N, 131072):                        # generated chunk-wise: no 8 GB temporaries
+        base[i:i + 131072] = torch.randn(min(131072, N - i), D, generator=g, device='cuda')
     qs = torch.randn(Q, D, generator=g, device='cuda')
     for q in range(Q):                                   # plant the positives near their query
         idx = torch.tensor(gnd[q]['easy'] + gnd[q]['hard'], device='cuda')
         base[idx] += qs[q] * torch.rand(len(idx), 1, generator=g, device='cuda') * 1.5
-    base = torch.nn.functional.normalize(base, dim=1)
+    for i in range(0, N, 131072):
+        base[i:i + 131072] = torch.nn.functional.normalize(base[i:i + 131072], dim=1)
     qs = torch.nn.functional.normalize(qs, dim=1)
     scores = ranking.similarity_device(qs, base)
-    assert scores.shape == (Q, Nb + Nd)
-    dev = ranking.eval_aps_device(db, scores)
+    assert scores.shape == (Q, N)
+    cols = torch.from_numpy(r.choice(N, 512, replace=False)).cuda()
+    ref = (qs.double() @ base[cols].double().t()).cpu().numpy()
+    got = scores[:, cols].cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6, np.abs(got - ref).max()      # fp32 chain over K = 2048, |s| <= 1
+    tables = ranking.build_probe_tables(db)
+    dev = ranking.eval_aps_device(db, scores, tables)
     sc = scores.cpu().numpy()
     for q in (0, 1, 2, 35, 69):
         host = db.eval_query_AP(q, sc[q])
@@ -97,3 +107,87 @@ def test_million_distractors_ranking(tmp_path):
             assert dev[q][m] == pytest.approx(host[m], abs=1e-12), (q, m)
     med = np.mean([d['medium'] for d in dev if d['medium'] >= 0])
     assert 0.05 < med <= 1.0
+
+
+def test_many_probes_per_query(tmp_path):
+    """More than 1024 listed images for a query (RParis6K has queries with > 1000 positives + junk):
+    the probe list spans several kernel launches; device AP still equals the host protocol."""
+    from dirtorch_amd import ranking
+    r = np.random.RandomState(4)
+    N, Q = 20000, 3
+    db, gnd = make_db(tmp_path, N, Q, r, npos=1500, njunk=700)
+    scores = r.standard_normal((Q, N)).astype(np.float32)
+    scores[0, gnd[0]['easy'][0]] = scores[0, gnd[0]['junk'][0]]      # a positive tied with a junk image
+    host = [db.eval_query_AP(q, scores[q]) for q in range(Q)]
+    dev = ranking.eval_aps_device(db, torch.from_numpy(scores).cuda())
+    for h, d in zip(host, dev):
+        for m in ('easy', 'medium', 'hard'):
+            assert d[m] == pytest.approx(h[m], abs=1e-12), m
+
+
+# ---- N3: alpha query expansion / database augmentation ------------------------------------------------
+from test_oracle_golden import QE_CASES, qe_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize('k,alpha', QE_CASES)
+def test_expand_descriptors_vs_reference_golden(k, alpha, qe_goldens):
+    """dirtorch_amd.test_dir.expand_descriptors (top-k + weighted mean + L2 on the GPU) against outputs
+    of the reference's expand_descriptors (test_dir.py:24-44): the --adba form (self-set, diagonal
+    zeroed) and the --aqe form (db=)."""
+    from dirtorch_amd import test_dir as td
+    q, db = qe_inputs()
+    got_self = td.expand_descriptors(db.copy(), alpha=alpha, k=k)
+    got_db = td.expand_descriptors(q.copy(), db=db.copy(), alpha=alpha, k=k)
+    assert isinstance(got_self, np.ndarray) and got_self.dtype == np.float32
+    np.testing.assert_allclose(got_self, qe_goldens['qe.self.k%d.a%d' % (k, alpha)], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got_db, qe_goldens['qe.db.k%d.a%d' % (k, alpha)], rtol=0, atol=2e-6)
+    assert td.expand_descriptors(q, db=db, alpha=alpha, k=0) is q
+    assert td.expand_descriptors(torch.from_numpy(q), db=torch.from_numpy(db), alpha=alpha, k=k).shape == q.shape
+
+
+def test_expand_descriptors_at_dataset_scale_and_errors():
+    """ROxford5K-sized DBA (4993 x 2048, k = 10, alpha = 3) and AQE (70 queries) against the oracle; the
+    row-chunked path (scratch smaller than the score matrix); argument errors."""
+    import dir_oracle as O
+    import synth
+    from dirtorch_amd import ops
+    from dirtorch_amd import test_dir as td
+    db = synth.synth_descriptors(41, 4993, 2048, clusters=40)
+    q = synth.synth_descriptors(42, 70, 2048, clusters=40)
+    ref_q = O.expand_descriptors(q, db=db, alpha=3, k=10)
+    got_q = td.expand_descriptors(q, db=db, alpha=3, k=10)
+    assert np.all(1 - O.cosine(got_q, ref_q) < 1e-6)
+    sub = db[:600]
+    ref_s = O.expand_descriptors(sub.copy(), alpha=2, k=7)
+    got_s = td.expand_descriptors(sub.copy(), alpha=2, k=7)
+    assert np.all(1 - O.cosine(got_s, ref_s) < 1e-6)
+    chunked = ops.expand_descriptors(torch.from_numpy(sub).cuda(), None, alpha=2.0, k=7,
+                                     scratch_bytes=37 * 600 * 4).cpu().numpy()      # 37 rows per pass
+    assert np.array_equal(chunked, got_s)
+    with pytest.raises(ValueError):
+        td.expand_descriptors(q[:5], db=db[:3], alpha=1, k=4)            # k > candidates, as np.argpartition
+    with pytest.raises(AssertionError):
+        td.expand_descriptors(q, db=db, alpha=-1, k=2)
+
+
+def test_descriptor_widths_that_are_not_multiples_of_four(postproc_goldens):
+    """--whitenv N with N % 4 != 0 (the reference accepts any N, common.py:226): whitening to 50 / 127
+    components and the similarity of those descriptors run through the element-wise gather of the
+    fp32 GEMM and agree with the oracle."""
+    import dir_oracle as O
+    from dirtorch_amd.utils import common
+    G = postproc_goldens
+    pca = O.PCAParams(G['pca.mean'], G['pca.components'], G['pca.var'], True)
+    X = G['whiten.in']
+    for v in (50, 31, 1):
+        ref = O.whiten_features(X, pca, whitenp=0.25, whitenv=v)
+        got = common.whiten_features(X, pca, whitenp=0.25, whitenv=v)
+        assert got.shape == ref.shape == (X.shape[0], v)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        s_ref = O.matmul(ref[:7], ref)
+        s_got = common.matmul(got[:7], got)
+        np.testing.assert_allclose(s_got, s_ref, rtol=0, atol=5e-5)
+    r = np.random.RandomState(9)
+    A = r.standard_normal((70, 127)).astype(np.float32)
+    B = r.standard_normal((300, 127)).astype(np.float32)
+    np.testing.assert_allclose(common.matmul(A, B), A.astype(np.float64) @ B.astype(np.float64).T, rtol=0, atol=5e-5)
