@@ -94,6 +94,11 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'dir_expand_descriptors': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    'dir_comm_init_all': (c_int, [c_int, POINTER(c_int), POINTER(c_void_p)]),
+    'dir_comm_size': (c_int, [c_void_p, POINTER(c_int)]),
+    'dir_comm_destroy': (c_int, [c_void_p]),
+    'dir_allgather_desc': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_int,
+                                   POINTER(c_void_p)]),
     'dir_multiscale_pool': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                     c_void_p]),
 }

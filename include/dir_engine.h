@@ -255,6 +255,23 @@ int dir_revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, cons
 int dir_expand_descriptors(const float* descs, int n, const float* db, int m, int D, int k, float alpha,
                            int self_set, float* out, float* sim, size_t sim_bytes, void* stream);
 
+/* ---- the exchange step ------------------------------------------------------------
+ * All-gather of per-GPU descriptor blocks over RCCL / xGMI for ONE process driving several GPUs - the
+ * shape of the reference's nn.DataParallel use (dirtorch/utils/common.py:150-175).  One process per
+ * GPU reaches the same collective through torch.distributed (dirtorch_amd/distributed.py).  librccl is
+ * bound at first use (dlopen): without it these calls fail with DIR_ERR_STATE, nothing else changes.
+ *   dir_comm_init_all   ncclCommInitAll over devices[0..ndev) (NULL = 0..ndev-1)
+ *   dir_allgather_desc  rank i contributes send[i] = [rows][D] fp32 on device i and receives
+ *                       recv[i] = [ndev*rows][D] (rank order = shard order; equal `rows` per rank - the
+ *                       caller pads the last shard and trims after, as distributed.py does);
+ *                       streams[i] = the stream of device i to enqueue on (NULL array = default streams) */
+typedef struct dir_comm dir_comm;
+int dir_comm_init_all(int ndev, const int* devices, dir_comm** out);
+int dir_comm_size(const dir_comm* c, int* ndev);
+int dir_comm_destroy(dir_comm* c);
+int dir_allgather_desc(dir_comm* c, const float* const* send, float* const* recv, size_t rows, int D,
+                       void* const* streams);
+
 #ifdef __cplusplus
 }
 #endif
