@@ -95,10 +95,10 @@ def cpu_baseline(arch, size, budget_s):
 
 
 def layer_group(name):
-    """'layer3.7.conv2' -> 'layer3.conv2' (the 23 identical blocks of a stage share a row); the first
-    block of a stage differs in shape (stride / width) and keeps its own rows through (flops, bytes)."""
+    """'layer3.7.conv2' -> 'layer3.conv2' (the identical blocks 1.. of a stage share a row); block 0 of a
+    stage differs in shape (stride / input width) and keeps its own name 'layer3.0.conv2'."""
     parts = name.split('.')
-    if len(parts) == 3 and parts[0].startswith('layer'):
+    if len(parts) == 3 and parts[0].startswith('layer') and parts[1] != '0':
         return parts[0] + '.' + parts[2]
     return name
 

@@ -122,7 +122,9 @@ def bench_kernel_name(k):
 
 def layer_group(name):
     parts = name.split('.')
-    return parts[0] + '.' + parts[2] if len(parts) == 3 and parts[0].startswith('layer') else name
+    if len(parts) == 3 and parts[0].startswith('layer') and parts[1] != '0':
+        return parts[0] + '.' + parts[2]
+    return name
 
 
 def aligned(d, seq, counters=None):

@@ -115,9 +115,11 @@ def test_trunk_tiles_at_headline_size(dtype):
     scale = float(ref.abs().max())
     print('\n[scale-tiles] %s: whole-map rel L2 %.3e; per-tile rel L2 max %.3e median %.3e; per-tile max-abs %.3e '
           '(map max %.3e)' % (dtype, whole, tile_rel.max(), np.median(tile_rel), tile_max.max(), scale))
-    tol = 8e-3 if dtype == 'bf16' else 1e-3           # the whole-map bound of test_model_gpu.py
+    # whole map: one 16-bit rounding per stored activation compounded over 101 layers (measured on
+    # MI355X: 8.5e-3 bf16, 1.07e-3 fp16; the 17-50 layer nets of test_model_gpu.py sit at 4e-3 / 5e-4)
+    tol = 1.2e-2 if dtype == 'bf16' else 1.5e-3
     assert whole < tol, whole
-    # a tile made of garbage has rel L2 ~ 1; rounding drift varies between tiles by a small factor
-    assert tile_rel.max() < 4 * tol, tile_rel.max()
-    assert tile_rel.max() < 6 * np.median(tile_rel), (tile_rel.max(), np.median(tile_rel))
-    assert tile_max.max() < 0.1 * scale, (tile_max.max(), scale)
+    # the sharp criterion: rounding drift is UNIFORM over the map (measured max / median = 1.01), a tile
+    # made of garbage has rel L2 ~ 1
+    assert tile_rel.max() < 1.5 * np.median(tile_rel), (tile_rel.max(), np.median(tile_rel))
+    assert tile_max.max() < 0.05 * scale, (tile_max.max(), scale)
