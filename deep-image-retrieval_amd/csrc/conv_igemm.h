@@ -20,6 +20,11 @@ struct ConvArgs {
     // partial[z][M][Cout]; conv_splitk_finalize adds them in z order with bias / residual / ReLU.
     int ksplit;      // 0 or 1 = off
     float* partial;
+    // fused bottleneck seam (conv_c3c1.hip): the NEXT block's conv1 applied to this conv's output tile
+    const uint16_t* w2;    // [Cout2][Cout]
+    const float* bias2;    // [Cout2]
+    uint16_t* y2;          // NHWC [B,OH,OW,Cout2]
+    int Cout2, relu2;
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)
@@ -37,14 +42,17 @@ struct ConvVariant {
     ConvLaunchFn launch16[2];  // Cin == 16 stem instantiation, or nullptr
     int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip),
                                // 2 = persistent 256x256 1x1 (conv_persist.hip),
-                               // 3 = register-stationary weights 1x1 (conv_wreg.hip)
+                               // 3 = register-stationary weights 1x1 (conv_wreg.hip),
+                               // 4 = kind 2 with the pixel operand three K-steps deep (conv_persist.hip, XDEEP)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
 };
 
 bool conv1x1_persist_admissible(const ConvArgs& a);
-hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream, bool xdeep = false);
 bool conv1x1_wreg_admissible(const ConvArgs& a);
 hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+bool conv_c3c1_admissible(const ConvArgs& a);
+hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

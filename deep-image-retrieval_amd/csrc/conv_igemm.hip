@@ -467,6 +467,8 @@ static const ConvVariant kVariants[] = {
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}},
+    // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
+    {"256x256_persist1x1_x3", 256, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 4, {nullptr, nullptr}},
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
     {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}},
 };
@@ -480,6 +482,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     const ConvVariant& cv = kVariants[v];
     if (cv.kind == 1) return a.Cout == cv.BN && conv_patch3x3_admissible(a);
     if (cv.kind == 2) return conv1x1_persist_admissible(a);
+    if (cv.kind == 4) return conv1x1_persist_admissible(a) && a.res == nullptr;   // the deep-X form has no residual path
     if (cv.kind == 3) return conv1x1_wreg_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
@@ -524,7 +527,9 @@ int conv_pick_variant(const ConvArgs& a) {
         c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     } else if (a.Cout % 256 == 0 && T >= 6) {
         // 3x3: 16 waves of 64x64; 1x1: the persistent kernel (falls through when not admissible)
-        c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : "256x256_persist1x1", 1};
+        // 1x1 without a residual (the N -> N/4 conv1 of a bottleneck, downsample): the deep-X ring
+        static const bool no_x3 = getenv("DIRTORCH_AMD_NO_X3") != nullptr;      // A/B and bisecting
+        c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (!a.res && !no_x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
         // loop; with fewer than ~100 tiles even that leaves CUs idle and split-K takes over
@@ -643,6 +648,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     }
     hipError_t e = cv.kind == 1   ? conv_patch3x3_launch(a, dtype, stream)
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
+                   : cv.kind == 4 ? conv1x1_persist_launch(a, dtype, stream, true)
                    : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);

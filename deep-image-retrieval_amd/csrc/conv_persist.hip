@@ -27,14 +27,24 @@ __device__ __forceinline__ uint32_t fast_div_q(uint32_t n, uint32_t mul, uint32_
     return mul ? (__umulhi(n, mul) >> shr) : n;
 }
 
-template <class DT>
+// XDEEP = false: the map above (2 slots of X+W).
+// XDEEP = true : THREE slots for the pixel operand, two for the weights, K-step still 64:
+//     X slots [0,32K) [32K,64K) [64K,96K), W slots [96K,128K) [128K,160K); staging [32K,100K).
+//   The weight half of every stage is an L2 hit, the pixel half comes from HBM: with one 64 KB stage in
+//   flight only 32 KB per CU are HBM requests, and 32 KB / ~2.5 us of loaded latency x 256 CUs is the
+//   3.9 TB/s the 1024 -> 256 convs of layer3 were measured at (profiles/r02_*_kernel_roofline.txt).  Here
+//   X runs two K-steps ahead and W one (issue order W(t+1), X(t+2); the wait before step t leaves exactly
+//   X(t+1) - the newest ops, all of the LDS-DMA kind - in flight), so 64-96 KB of HBM requests per CU
+//   are outstanding.  Next tile's W(0) / X(0) still go out before the epilogue, X(1) right after it.
+template <class DT, bool XDEEP, bool RES>
 __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) {
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int TM = 2, TN = 4;              // wave tile 64 pixels x 128 channels (4 x 2 waves)
     constexpr int NA = 4, NB = 4;              // DMA instructions per lane per stage (X, W)
     constexpr int XS = BM * 128, STAGE = (BM + BN) * 128;   // 32 KiB + 32 KiB
     constexpr int EROW = 2 * 128 + 16;         // staging row: 64 fp32 + pad
-    constexpr int EPI_OFF = STAGE;             // staging lives above slot 0
+    constexpr int EPI_OFF = XDEEP ? XS : STAGE;   // staging: above slot 0 / above X slot 0
+    constexpr int WOFF = 3 * XS;               // XDEEP: first weight slot
     typedef typename DT::frag_t frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,25 +89,56 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         for (int i = 0; i < NB; ++i)
             wvoff[i] = (uint32_t)(((tile_n * BN + i * 64 + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
     };
-    auto issue = [&](int t, char* stage) {
+    auto issue_x = [&](int t, char* dst) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) dma16q(rsrc_x, stage + (i * NT + wave * 64) * 16, xvoff[i], t * 128);
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            dma16q(rsrc_w, stage + XS + (i * NT + wave * 64) * 16, wvoff[i], t * 128);
+        for (int i = 0; i < NA; ++i) dma16q(rsrc_x, dst + (i * NT + wave * 64) * 16, xvoff[i], t * 128);
     };
+    auto issue_w = [&](int t, char* dst) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) dma16q(rsrc_w, dst + (i * NT + wave * 64) * 16, wvoff[i], t * 128);
+    };
+    auto issue = [&](int t, char* stage) {
+        issue_x(t, stage);
+        issue_w(t, stage + XS);
+    };
+    // XDEEP slot addresses: X(t) -> slot t % 3, W(t) -> slot (t + 1) & 1 (so a tile's W(0) sits in the
+    // slot the staging area never touches)
+    auto xslot = [&](int t) { return smem + (t % 3) * XS; };
+    auto wslot = [&](int t) { return smem + WOFF + ((t + 1) & 1) * XS; };
 
     const int lswz = (lane >> 1) & 7;
     int loff[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) loff[ks] = lrow * 128 + (((2 * ks + lhi) ^ lswz) << 4);
     const int xfrag = (wm * TM * 32) * 128;
-    const int wfrag = XS + (wn * TN * 32) * 128;
+    const int wfrag = (XDEEP ? 0 : XS) + (wn * TN * 32) * 128;
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
+    // The bias of a tile (its accumulators start there) is fetched BEFORE that tile's first DMA goes
+    // out: the compiler waits for ordinary loads in program order, so a bias load issued after the
+    // prefetches would drag a wait for all of them to the top of every tile.
+    // (64 registers: only the residual-free deep-X form has them to spare; the other form loads the bias
+    // at the top of the tile as before.)
+    f32x4_t bz[XDEEP ? TN : 1][XDEEP ? 4 : 1];
+    auto load_bias = [&](int t) {
+        if (!XDEEP) return;
+        const int nw = (t % a.tiles_n) * BN + wn * TN * 32;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bz[XDEEP ? i : 0][XDEEP ? g : 0] = *(const DIR_GLOBAL f32x4_t*)(a.bias + nw + i * 32 + 8 * g + 4 * lhi);
+    };
+    load_bias(tile);
     tile_offsets(tile);
-    issue(0, smem);  // first tile: stage 0 -> slot 0
+    if (XDEEP) {
+        issue_w(0, wslot(0));
+        issue_x(0, xslot(0));
+        if (T > 1) issue_x(1, xslot(1));
+    } else {
+        issue(0, smem);  // first tile: stage 0 -> slot 0
+    }
 
     for (;;) {
         const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
@@ -109,7 +150,8 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_wave + i * 32 + 8 * g + 4 * lhi);
+                const f32x4_t b4 = XDEEP ? bz[XDEEP ? i : 0][XDEEP ? g : 0]
+                                         : *(const DIR_GLOBAL f32x4_t*)(a.bias + n_wave + i * 32 + 8 * g + 4 * lhi);
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -118,8 +160,9 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
 
         // residual tile of this wave: 2 strips x 2 channel halves x 4 passes of 16 B per lane
         const int ecol = (lane & 7) * 8, erow = lane >> 3;
-        u32x4_t rres[TM][2][4];
-        if (a.res) {
+        // RES = false instantiations (the deep-X form) carry no residual registers: 64 VGPRs less
+        u32x4_t rres[RES ? TM : 1][2][RES ? 4 : 1];
+        if (RES && a.res) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -128,11 +171,39 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
                     for (int pass = 0; pass < 4; ++pass) {
                         const int m = m_epi + j * 32 + pass * 8 + erow;
                         const int mc = m < a.M ? m : 0;
-                        rres[j][h][pass] = gload16(a.res + ((size_t)mc * a.Cout + n_wave + h * 64 + ecol));
+                        rres[RES ? j : 0][h][RES ? pass : 0] = gload16(a.res + ((size_t)mc * a.Cout + n_wave + h * 64 + ecol));
                     }
         }
 
         // ---- K loop: stage 0 is already in flight (issued by the previous tile or the preamble) --
+        if (XDEEP) {
+            for (int t = 0; t < T; ++t) {
+                // need X(t), W(t); may leave X(t+1) - the 4 newest ops, same kind - in flight.  With a
+                // residual the tile's first wait also covers the (newer, VGPR-kind) residual loads.
+                if (t + 1 < T && !(RES && t == 0 && a.res)) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();  // step t landed everywhere; X slot (t+2)%3 and W slot of t+1 are free
+                if (t + 1 < T) issue_w(t + 1, wslot(t + 1));
+                if (t + 2 < T) issue_x(t + 2, xslot(t + 2));
+                const char* xs = xslot(t);
+                const char* ws = wslot(t);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    frag_t wf[TN], xf[TM];
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) wf[i] = *(const frag_t*)(ws + wfrag + i * 4096 + loff[ks]);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) xf[j] = *(const frag_t*)(xs + xfrag + j * 4096 + loff[ks]);
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j) acc[i][j] = DT::mfma32(wf[i], xf[j], acc[i][j]);
+                }
+            }
+        } else {
         int issued = 1;
         for (int t = 0; t < T; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -155,13 +226,20 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
                     for (int j = 0; j < TM; ++j) acc[i][j] = DT::mfma32(wf[i], xf[j], acc[i][j]);
             }
         }
-        __syncthreads();  // both slots are dead
+        }
+        __syncthreads();  // every slot is dead
 
         // ---- next tile's first stage goes out before this tile's epilogue -------------------------
         const int next = tile + (int)gridDim.x;
         if (next < ntiles) {
+            load_bias(next);
             tile_offsets(next);
-            issue(0, smem);
+            if (XDEEP) {
+                issue_w(0, wslot(0));
+                issue_x(0, xslot(0));
+            } else {
+                issue(0, smem);
+            }
         }
 
         // ---- epilogue through the staging area above slot 0 ---------------------------------------
@@ -190,8 +268,8 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
                     const int m = m_epi + j * 32 + mrow;
                     if (m < a.M) {
                         float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-                        if (a.res) {
-                            const u32x4_t rv = rres[j][h][pass];
+                        if (RES && a.res) {
+                            const u32x4_t rv = rres[RES ? j : 0][h][RES ? pass : 0];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float lo, hi;
@@ -215,6 +293,13 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         if (next >= ntiles) break;
+        if (XDEEP && T > 1) {
+            // every wave is done with the staging area (it covers X slot 1).  Raw barrier: __syncthreads()
+            // would drain vmcnt, i.e. wait for the stage already in flight and for this tile's stores.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_x(1, xslot(1));
+        }
         tile = next;
     }
 }
@@ -223,11 +308,13 @@ bool conv1x1_persist_admissible(const ConvArgs& a) {
     return a.R == 1 && a.S == 1 && a.pad == 0 && a.Cout % 256 == 0 && a.Cin % 64 == 0 && a.Cin >= 128;
 }
 
-template <class DT>
+template <class DT, bool XDEEP>
 static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
-    constexpr int LDS = (256 + 256) * 128 + 8 * 32 * (2 * 128 + 16);  // slot 0 + staging (covers slot 1)
+    // 2-slot map: slot 0 + staging (covers slot 1); deep-X map: 3 X slots + 2 W slots = all 160 KiB
+    constexpr int LDS = XDEEP ? 5 * 256 * 128 : (256 + 256) * 128 + 8 * 32 * (2 * 128 + 16);
     static_assert(LDS >= 2 * (256 + 256) * 128 && LDS <= 160 * 1024, "LDS map");
-    auto kern = conv1x1_persist_kernel<DT>;
+    static_assert(!XDEEP || 256 * 128 + 8 * 32 * (2 * 128 + 16) <= 3 * 256 * 128 + 256 * 128, "staging must end below W slot 1");
+    auto kern = conv1x1_persist_kernel<DT, XDEEP, !XDEEP>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -260,8 +347,9 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
-    return dtype == DIR_BF16 ? launch_persist<BF16>(a, stream) : launch_persist<FP16>(a, stream);
+hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream, bool xdeep) {
+    if (xdeep) return dtype == DIR_BF16 ? launch_persist<BF16, true>(a, stream) : launch_persist<FP16, true>(a, stream);
+    return dtype == DIR_BF16 ? launch_persist<BF16, false>(a, stream) : launch_persist<FP16, false>(a, stream);
 }
 
 }  // namespace dir

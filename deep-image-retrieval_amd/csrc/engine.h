@@ -75,6 +75,10 @@ struct dir_engine {
                 int* fh, int* fw, int* fc, void* ws, size_t ws_bytes, hipStream_t stream);
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
                  int H, int W, int OH, int OW, hipStream_t stream);
+    // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes
+    // do not qualify and nothing was launched
+    int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
+                 uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used);
     float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
                    hipStream_t stream);

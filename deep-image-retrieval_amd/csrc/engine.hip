@@ -407,6 +407,55 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
     return prof_end(stream);
 }
 
+// ---- fused bottleneck seam ----------------------------------------------------------------------------
+int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
+                         uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used) {
+    *used = 0;
+    // DIRTORCH_AMD_C3C1: "0" = never (A/B and bisecting), "force" = whenever the shapes qualify, default =
+    // when every persistent workgroup gets at least ~4 pixel tiles to amortise loading both weight sets
+    const char* mode = getenv("DIRTORCH_AMD_C3C1");   // read per call: tests toggle it
+    if (mode && mode[0] == '0') return DIR_OK;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = t2;
+    a.w = c3.d_w;
+    a.bias = c3.d_bias;
+    a.res = res;
+    a.y = y;
+    a.B = B;
+    a.H = a.OH = H;
+    a.W = a.OW = W;
+    a.Cin = c3.Cin;
+    a.Cout = c3.Cout;
+    a.R = c3.R;
+    a.S = c3.S;
+    a.stride = c3.stride;
+    a.pad = c3.pad;
+    a.relu = c3.relu ? 1 : 0;
+    a.M = B * H * W;
+    a.Ktot = a.Cin;
+    a.w2 = c1.d_w;
+    a.bias2 = c1.d_bias;
+    a.y2 = t1;
+    a.Cout2 = c1.Cout;
+    a.relu2 = c1.relu ? 1 : 0;
+    if (c1.R != 1 || c1.S != 1 || c1.stride != 1 || c1.pad != 0 || c1.Cin != c3.Cout || !conv_c3c1_admissible(a))
+        return DIR_OK;
+    const bool force = mode && mode[0] == 'f';
+    if (!force && (a.M + 63) / 64 < 1024) return DIR_OK;
+    const double macs = (double)a.M * ((double)c3.Cout * c3.Cin + (double)c1.Cout * c1.Cin);
+    const double bytes = 2.0 * ((double)a.M * (c3.Cin + 2.0 * c3.Cout + c1.Cout) + (double)c3.Cout * c3.Cin +
+                                (double)c1.Cout * c1.Cin);
+    // profile row "layerS.J.c3c1": conv3 of block J + conv1 of block J+1
+    int rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".c3c1", "conv_c3c1<" + std::to_string(c3.Cin) + ">",
+                        2.0 * macs, bytes, stream);
+    if (rc != DIR_OK) return rc;
+    hipError_t e = conv_c3c1_launch(a, dtype, stream);
+    if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv_c3c1 launch: ") + hipGetErrorString(e));
+    *used = 1;
+    return prof_end(stream);
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* desc_out,
                         void* feat_out, int* fh, int* fw, int* fc, void* ws, size_t ws_bytes,
@@ -476,6 +525,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
     uint16_t* x4 = nullptr;
     int h = p.PH, w = p.PW, h4 = 0, w4 = 0;
+    bool t1_ready = false;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
@@ -488,12 +538,26 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             resid = ds;
         }
         if (desc.bottleneck) {
-            rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream);
-            if (rc != DIR_OK) return rc;
+            if (!t1_ready) {   // (the previous block's fused seam kernel may have produced t1 already)
+                rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream);
+                if (rc != DIR_OK) return rc;
+            }
+            t1_ready = false;
             rc = run_conv(convs[bd.conv2], t1, nullptr, t2, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
-            rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
-            if (rc != DIR_OK) return rc;
+            int fused = 0;
+            if (bi + 1 < blocks.size() && blocks[bi + 1].down < 0 && blocks[bi + 1].stride == 1 && !tuning) {
+                // conv3 + the next block's conv1 in one kernel: the block output is not re-read (conv_c3c1.hip)
+                rc = run_seam(convs[bd.conv3], convs[blocks[bi + 1].conv1], t2, resid, nxt, t1, B, oh, ow, stream,
+                              &fused);
+                if (rc != DIR_OK) return rc;
+            }
+            if (fused) {
+                t1_ready = true;
+            } else {
+                rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
+                if (rc != DIR_OK) return rc;
+            }
         } else {
             rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;

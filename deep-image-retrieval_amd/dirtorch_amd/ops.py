@@ -91,6 +91,18 @@ def conv_bn_act(x, w, bias, res=None, stride=1, pad=0, relu=True, out_hw=None, v
     return y
 
 
+def conv_c3c1(t2, w3, bias3, res, w1, bias1, relu3=True, relu1=True):
+    """Fused bottleneck seam (dir_conv_c3c1): returns (y [B,H,W,4P], t1 [B,H,W,P]).
+    t2 [B,H,W,P], w3 [4P,1,1,P] or [4P,P], res [B,H,W,4P], w1 [P,1,1,4P] or [P,4P]; 16-bit NHWC, fp32 biases."""
+    _need_cuda(t2, w3, bias3, res, w1, bias1)
+    B, H, W, P = t2.shape
+    y = torch.empty(B, H, W, 4 * P, dtype=t2.dtype, device=t2.device)
+    t1 = torch.empty(B, H, W, P, dtype=t2.dtype, device=t2.device)
+    call('dir_conv_c3c1', ptr(t2), ptr(w3), ptr(bias3), ptr(res), ptr(y), ptr(w1), ptr(bias1), ptr(t1), B, H, W, P,
+         int(bool(relu3)), int(bool(relu1)), _dtype_code(t2), stream_ptr())
+    return y, t1
+
+
 def prep_input(img, dtype=torch.bfloat16, mean=None, std=None):
     """fp32 NCHW (normalised) or uint8 NHWC image batch -> space-to-depth NHWC16 stem input."""
     _need_cuda(img)

@@ -161,6 +161,15 @@ int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, cons
                            int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                            int OH, int OW, int relu, int dtype, int variant, int ksplit, void* scratch,
                            size_t scratch_bytes, int* ksplit_used, void* stream);
+/* The seam between two bottlenecks as ONE kernel (csrc/conv_c3c1.hip), planes P = 64 or 128:
+ *   y  = act3(conv1x1(t2; w3 [4P][P]) + bias3 + res)      the conv3 + bn3 + add + ReLU that closes a block
+ *   t1 = act1(conv1x1(y;  w1 [P][4P]) + bias1)            the conv1 + bn1 + ReLU that opens the next one
+ * (dirtorch/nets/backbones/resnet.py:78-85 then :70-72).  t2 [B,H,W,P], res / y [B,H,W,4P], t1 [B,H,W,P],
+ * NHWC 16-bit; conv1 consumes the ROUNDED y, so the pair equals two dir_conv_bn_act calls up to fp32
+ * summation order.  The engine uses it for the layer1 / layer2 seams when the map has >= 65536 pixels. */
+int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void* res, void* y, const void* w1,
+                  const float* bias1, void* t1, int B, int H, int W, int P, int relu3, int relu1, int dtype,
+                  void* stream);
 /* Slow, obviously-correct direct convolution with the same contract (device-side checker). */
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res,
                           void* y, int B, int H, int W, int Cin, int Cout, int R, int S,

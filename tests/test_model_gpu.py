@@ -211,3 +211,38 @@ def test_register_stationary_conv3_inside_the_network():
     # against the quantised oracle (measured 4e-3)
     assert rel < 8e-3, rel
     assert float((got - ref).abs().max()) < 0.05 * float(ref.abs().max())
+
+
+def test_fused_seams_inside_the_network(monkeypatch):
+    """ResNet-50 at 4 x 512^2: layer1 (128^2 maps, 65536 pixels) and - forced - layer2 run their
+    conv3 -> next-conv1 seams through conv_c3c1.hip.  The feature map must equal the un-fused network's
+    up to 16-bit rounding flips (the fused kernel feeds conv1 the same rounded tensor it stores), and the
+    profile must show the fused launches."""
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet50', seed=7)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randint(0, 256, (4, 512, 512, 3), generator=g, dtype=torch.uint8, device='cuda')
+
+    def run(mode, dtype):
+        monkeypatch.setenv('DIRTORCH_AMD_C3C1', mode)
+        net = make_net('resnet50', {}, sd, dtype)
+        f = net.forward_features(x).float()
+        net.set_profiling(True)
+        d = net(x)
+        names = {r['name']: r['kernel'] for r in net.get_profile()}
+        return f, d, names
+
+    for dtype, tol in (('bf16', 8e-3), ('fp16', 1e-3)):
+        f_ref, d_ref, n_ref = run('0', dtype)
+        f_fus, d_fus, n_fus = run('force', dtype)
+        assert not any('c3c1' in k for k in n_ref.values())
+        assert n_fus.get('layer1.0.c3c1') == 'conv_c3c1<64>' and n_fus.get('layer2.1.c3c1') == 'conv_c3c1<128>', n_fus
+        assert 'layer1.1.conv1' not in n_fus and 'layer1.0.conv3' not in n_fus      # replaced, not duplicated
+        assert 'layer2.0.conv1' in n_fus and 'layer1.2.conv3' in n_fus              # stage boundaries stay two kernels
+        assert torch.isfinite(f_fus).all()
+        rel = float((f_fus - f_ref).norm() / f_ref.norm())
+        assert rel < tol, (dtype, rel)
+        assert np.all(1 - O.cosine(d_fus.cpu().numpy(), d_ref.cpu().numpy()) < 1e-5)
+    # default mode: on by itself where the map is large enough (layer1 at 512^2 x 4 = 65536 pixels)
+    _, _, n_def = run('auto', 'bf16')
+    assert n_def.get('layer1.0.c3c1') == 'conv_c3c1<64>', n_def

@@ -44,6 +44,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
         return k == 1 and stride == 1 and pad == 0 and Cout % 512 == 0 and Cin in (128, 256) and has_res
     if 'patch3x3' in name:
         return k == 3 and stride == 1 and pad == 1 and Cin == Cout == bn
+    if 'persist1x1_x3' in name:          # the deep-X form has no residual path
+        return k == 1 and pad == 0 and Cout % 256 == 0 and Cin >= 128 and not has_res
     if 'persist1x1' in name:
         return k == 1 and pad == 0 and Cout % 256 == 0 and Cin >= 128
     return Cout % bn == 0
@@ -457,6 +459,35 @@ def test_conv_full_size_vs_device_checker(shape):
     assert torch.equal(y2, y1 * 2)
 
 
+@pytest.mark.parametrize('B,HW,Cin,Cout,stride', [(32, 64, 1024, 256, 1), (31, 63, 1024, 256, 1), (8, 128, 512, 1024, 2),
+                                                  (16, 32, 2048, 512, 1)],
+                         ids=['layer3.conv1_b32', 'ragged', 'layer3.0.downsample', 'layer4.conv1'])
+def test_persistent_deep_x_ring_at_scale(B, HW, Cin, Cout, stride):
+    """conv_persist.hip's deep-X form (3 pixel slots + 2 weight slots, counted waits, next tile's first
+    stage issued before the epilogue and its second right after) where every persistent workgroup walks
+    SEVERAL tiles: against the naive device checker element by element, per 256-pixel tile, and bit for
+    bit against the 2-slot form it replaces (same tile, same K order, same fp32 sums)."""
+    ops = _ops()
+    names = ops.conv_variant_names()
+    dt = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(31)
+    x = torch.randn(B, HW, HW, Cin, generator=g, device='cuda').to(dt)
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g, device='cuda') * (2.0 / Cin) ** 0.5).to(dt)
+    bias = torch.randn(Cout, generator=g, device='cuda') * 0.1
+    kw = dict(stride=stride, pad=0, relu=True)
+    got = ops.conv_bn_act(x, w, bias, None, variant=names.index('256x256_persist1x1_x3'), **kw)
+    old = ops.conv_bn_act(x, w, bias, None, variant=names.index('256x256_persist1x1'), **kw)
+    ref = ops.conv_bn_act(x, w, bias, None, naive=True, **kw).float()
+    assert torch.equal(got, old)
+    err = (got.float() - ref).abs()
+    tol = RTOL['bf16'] * ref.abs() + RTOL['bf16'] * ref.abs().mean()
+    bad = (err > tol)
+    assert int(bad.sum()) == 0, 'bad elements %d, first bad pixel rows %s' % (
+        int(bad.sum()), bad.flatten(0, 2).any(dim=1).nonzero()[:8].flatten().tolist())
+    again = ops.conv_bn_act(x, w, bias, None, variant=names.index('256x256_persist1x1_x3'), **kw)
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize('shape', [(63, 128, 128, 512), (8, 128, 128, 512), (8, 64, 256, 1024)],
                          ids=lambda s: 'B%d_%d_K%d_N%d' % s)
 def test_wreg_persistent_kernel_first_tiles_at_scale(shape):
@@ -492,3 +523,52 @@ def test_wreg_persistent_kernel_first_tiles_at_scale(shape):
         d = (y1.float() - y2.float()).abs()
         assert bool(torch.isfinite(y1.float()).all()), rep
         assert float(d.max()) <= 2 * RTOL['bf16'] * float(y2.float().abs().max()), (rep, float(d.max()))
+
+
+# ---- fused bottleneck seam: conv3 (+res, ReLU) -> next conv1 (conv_c3c1.hip) ----------------------------
+# (B, H, W): one ragged tile set; more tiles than persistent workgroups (M = 25600 -> 400 tiles of 64 on
+# 256 CUs); a single partial tile
+SEAM_SHAPES = [(2, 37, 29), (4, 80, 80), (1, 5, 7)]
+
+
+@pytest.mark.parametrize('relu3', [True, False])
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('P', [64, 128])
+@pytest.mark.parametrize('B,H,W', SEAM_SHAPES)
+def test_fused_seam_vs_oracle_and_two_kernel_path(B, H, W, P, dname, relu3):
+    """dir_conv_c3c1 against (a) the fp32 CPU oracle of both convolutions on the same rounded operands
+    (the second one fed the ROUNDED output of the first, as the un-fused engine does) and (b) the two
+    dir_conv_bn_act launches it replaces, run on the fused kernel's own block output."""
+    ops = _ops()
+    dt = DTYPES[dname]
+    t2 = F.relu(_rand((B, H, W, P), 1)).to(dt)
+    w3 = _rand((4 * P, 1, 1, P), 2, (2.0 / P) ** 0.5).to(dt)
+    b3 = _rand((4 * P,), 3, 0.2)
+    res = F.relu(_rand((B, H, W, 4 * P), 4)).to(dt)
+    w1 = _rand((P, 1, 1, 4 * P), 5, (2.0 / (4 * P)) ** 0.5).to(dt)
+    b1 = _rand((P,), 6, 0.2)
+    y, t1 = ops.conv_c3c1(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), w1.cuda(), b1.cuda(), relu3=relu3, relu1=True)
+    torch.cuda.synchronize()
+    ref_y = conv_reference(t2, w3, b3, res, 1, 0, relu3)
+    check_close(y, ref_y, dname, 'seam: block output')
+    # conv1 of the next block sees exactly the 16-bit tensor that went to HBM
+    ref_t1 = conv_reference(y.cpu(), w1, b1, None, 1, 0, True)
+    check_close(t1, ref_t1, dname, 'seam: next conv1')
+    t1_two = ops.conv_bn_act(y, w1.cuda(), b1.cuda(), None, relu=True)
+    y_two = ops.conv_bn_act(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), relu=relu3)
+    check_close(t1, t1_two.float().cpu(), dname, 'seam vs two-kernel conv1')
+    check_close(y, y_two.float().cpu(), dname, 'seam vs two-kernel conv3')
+    # run-to-run identical (the K halves meet in a fixed order)
+    y2, t12 = ops.conv_c3c1(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), w1.cuda(), b1.cuda(), relu3=relu3, relu1=True)
+    assert torch.equal(y, y2) and torch.equal(t1, t12)
+
+
+def test_fused_seam_argument_errors():
+    from dirtorch_amd import _lib
+    ops = _ops()
+    t2 = torch.zeros(1, 8, 8, 256, dtype=torch.bfloat16, device='cuda')      # planes 256: weights do not fit registers
+    w3 = torch.zeros(1024, 1, 1, 256, dtype=torch.bfloat16, device='cuda')
+    res = torch.zeros(1, 8, 8, 1024, dtype=torch.bfloat16, device='cuda')
+    w1 = torch.zeros(256, 1, 1, 1024, dtype=torch.bfloat16, device='cuda')
+    with pytest.raises(_lib.DirError):
+        ops.conv_c3c1(t2, w3, torch.zeros(1024, device='cuda'), res, w1, torch.zeros(256, device='cuda'))
