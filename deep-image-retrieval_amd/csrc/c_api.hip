@@ -342,6 +342,32 @@ int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void
     DIR_CATCH
 }
 
+int dir_conv_c3c1_ds(const void* t2, const void* x, const void* wcat, const float* bias, void* y, const void* w1,
+                     const float* bias1, void* t1, int B, int H, int W, int relu3, int relu1, int dtype,
+                     void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, t2, wcat, bias, nullptr, y, B, H, W, 64, 256, 1, 1, 1, 0, H, W, relu3);
+    if (rc != DIR_OK) return rc;
+    if (!x || !w1 || !bias1 || !t1) return fail(DIR_ERR_INVALID, "conv_c3c1_ds: null pointer");
+    if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv_c3c1_ds: bad dtype");
+    a.x2 = (const uint16_t*)x;
+    a.Cin2 = 64;
+    a.w2 = (const uint16_t*)w1;
+    a.bias2 = bias1;
+    a.y2 = (uint16_t*)t1;
+    a.Cout2 = 64;
+    a.relu2 = relu1 ? 1 : 0;
+    if (!conv_c3c1_admissible(a)) return fail(DIR_ERR_INVALID, "conv_c3c1_ds: shape not admissible");
+    if (((uintptr_t)t2 & 15) || ((uintptr_t)x & 15) || ((uintptr_t)wcat & 15) || ((uintptr_t)y & 15) ||
+        ((uintptr_t)w1 & 15) || ((uintptr_t)t1 & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)bias1 & 15))
+        return fail(DIR_ERR_INVALID, "conv_c3c1_ds: tensors must be 16-byte aligned");
+    hipError_t e = conv_c3c1_launch(a, dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv_c3c1_ds launch: ") + hipGetErrorString(e));
+    return DIR_OK;
+    DIR_CATCH
+}
+
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res, void* y,
                           int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int OH, int OW, int relu, int dtype, void* stream) {

@@ -18,6 +18,13 @@
 //            out-tile by its register-resident slice of W1; the two K halves meet through the staging
 //            area in fp32 (fixed order: results are run-to-run identical); + bias + ReLU, 16-byte stores
 //
+// DS form (first block of layer1): the residual of that block is itself a 1x1 convolution of the block
+// input (downsample + BN, resnet.py:134-141).  Un-fused it writes a 4P-wide tensor that conv3 reads
+// straight back; here it is simply 64 more K of the same GEMM - out = relu([W3 | Wds] . [t2 ; x] + (b3 +
+// bds)) - so the block input (64 channels) is staged next to t2, the downsample weights sit in
+// registers next to W3, and the 4P-wide residual tensor never exists (2 x 4P bytes per pixel less, one
+// launch less; one 16-bit rounding less than the reference's storage points).
+//
 // conv1' consumes exactly the 16-bit values stored to HBM, so the result equals the two-kernel path up
 // to the fp32 summation order of the K halves.  Weights of layer3 (1 MB per seam) do not fit the 512 KB
 // register file: the seam there stays two kernels.
@@ -28,15 +35,17 @@ namespace dir {
 
 static constexpr uint32_t kOOBf = 0x80000000u;
 
-template <class DT, int P>
+template <class DT, int P, bool DS>
 __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     static_assert(P == 64 || P == 128, "planes");
+    static_assert(!DS || P == 64, "the downsample form is layer1's: 64 + 64 input channels");
+    constexpr int KA = P + (DS ? 64 : 0);       // phase A contraction length (t2 channels [+ block input])
     constexpr int C4 = 4 * P;                   // block width
     constexpr int BM = 64, NT = 512;
     constexpr int CW = C4 / 8;                  // phase A: output channels per wave (32 / 64)
     constexpr int TA = CW / 32;                 // ... as 32-channel MFMA tiles (1 / 2)
-    constexpr int KSA = P / 16;                 // phase A k-slices (4 / 8)
-    constexpr int XBUF = BM * P * 2;            // one t2 tile: P/64 blocks of [64 px][128 B]
+    constexpr int KSA = KA / 16;                // phase A k-slices (4 / 8)
+    constexpr int XBUF = BM * KA * 2;           // one t2 (+ x) tile: KA/64 blocks of [64 px][128 B]
     constexpr int NX = XBUF / 16 / NT;          // staging loads per lane per tile (1 / 2)
     constexpr int EROW = 32 * 4 + 16;           // staging row: 32 fp32 + pad
     constexpr int EPI_OFF = 2 * XBUF;
@@ -55,6 +64,8 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     const int lrow = lane & 31, lhi = lane >> 5;
 
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2 =      // DS: the block input [M][64]
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? a.x2 : a.x), 0, DS ? (uint32_t)((size_t)a.M * 128) : a.x_bytes, 0x00020000);
     const uint32_t y_bytes = (uint32_t)((size_t)a.M * C4 * 2);
     const uint32_t y2_bytes = (uint32_t)((size_t)a.M * P * 2);
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, y_bytes, 0x00020000);
@@ -73,7 +84,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     for (int i = 0; i < TA; ++i)
 #pragma unroll
         for (int ks = 0; ks < KSA; ++ks)
-            w3[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + i * 32 + lrow) * P + ks * 16 + 8 * lhi);
+            w3[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + i * 32 + lrow) * KA + ks * 16 + 8 * lhi);
     // phase B roles: P = 128: (n-tile = w & 3, K half = w >> 2), both 32-pixel strips;
     //                P =  64: (n-tile = w & 1, strip = (w >> 1) & 1, K half = w >> 2)
     const int nt = P == 128 ? (wave & 3) : (wave & 1);
@@ -108,8 +119,13 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     auto load_x = [&](int t, u32x4_t* xr) {
         const int m = t * BM + spix;
         const uint32_t base = m < a.M ? (uint32_t)((m * P + sslot * 8) * 2) : kOOBf;
+        if (DS) {   // block 0 = t2 row, block 1 = block-input row (both 64 channels = 128 bytes per pixel)
+            xr[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, 0, 0);
+            xr[NX - 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2, base, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, i * 128, 0);
+            for (int i = 0; i < NX; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, i * 128, 0);
+        }
     };
     auto store_x = [&](const u32x4_t* xr, char* buf) {
 #pragma unroll
@@ -131,7 +147,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     load_x(tile, xr);
     int cur = 0;
     u32x4_t rres0[TA * 2], rres1[TA * 2];
-    load_res(tile, 0, rres0);
+    if (!DS) load_res(tile, 0, rres0);
     store_x(xr, smem);
     __syncthreads();   // first tile staged, bias tables written
     for (;;) {
@@ -139,7 +155,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
         const int next = more ? tile + per : tile;   // last step: a harmless repeat
         load_x(next, xr);
         const int m0 = tile * BM;
-        load_res(tile, 1, rres1);
+        if (!DS) load_res(tile, 1, rres1);
         const char* xb = smem + cur * XBUF;
 
         // ================= phase A: out = relu(t2 . W3^T + bias3 + res) ================================
@@ -158,12 +174,14 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
                 for (int i = 0; i < TA; ++i) acc[i] = DT::mfma32(w3[i][ks], xf, acc[i]);
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            if (!DS) {
 #pragma unroll
-            for (int q = 0; q < TA * 2; ++q) {       // one wait for the strip's residual, requested long ago
-                if (j == 0) {
-                    asm volatile("" : "+v"(rres0[q]));
-                } else {
-                    asm volatile("" : "+v"(rres1[q]));
+                for (int q = 0; q < TA * 2; ++q) {   // one wait for the strip's residual, requested long ago
+                    if (j == 0) {
+                        asm volatile("" : "+v"(rres0[q]));
+                    } else {
+                        asm volatile("" : "+v"(rres1[q]));
+                    }
                 }
             }
 #pragma unroll
@@ -185,13 +203,15 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
                     const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
                     float v[8] = {f0[0] + b0[0], f0[1] + b0[1], f0[2] + b0[2], f0[3] + b0[3],
                                   f1[0] + b1[0], f1[1] + b1[1], f1[2] + b1[2], f1[3] + b1[3]};
-                    const u32x4_t rv = j == 0 ? rres0[i * 2 + pass] : rres1[i * 2 + pass];
+                    if (!DS) {
+                        const u32x4_t rv = j == 0 ? rres0[i * 2 + pass] : rres1[i * 2 + pass];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo, hi;
-                        DT::unpack(rv[e], lo, hi);
-                        v[2 * e] += lo;
-                        v[2 * e + 1] += hi;
+                        for (int e = 0; e < 4; ++e) {
+                            float lo, hi;
+                            DT::unpack(rv[e], lo, hi);
+                            v[2 * e] += lo;
+                            v[2 * e + 1] += hi;
+                        }
                     }
                     if (a.relu) {
 #pragma unroll
@@ -209,7 +229,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (j == 0) load_res(next, 0, rres0);   // next tile's strip 0, one tile ahead
+            if (!DS && j == 0) load_res(next, 0, rres0);   // next tile's strip 0, one tile ahead
         }
         __syncthreads();   // (1) the out-tile is complete
 
@@ -300,18 +320,22 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
 }
 
 bool conv_c3c1_admissible(const ConvArgs& a) {
-    // a = the conv3 of a bottleneck (1x1 s1 + residual) with the following block's conv1 attached
+    // a = the conv3 of a bottleneck (1x1 s1) with the following block's conv1 attached; its residual is
+    // either a tensor (a.res) or - DS form, planes 64 - the 64-channel block input a.x2, whose
+    // downsample weights are concatenated to a.w along K ([Cout][64 + 64]) and biases summed in a.bias
+    const bool ds = a.x2 != nullptr;
     return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
-           (a.Cin == 64 || a.Cin == 128) && a.Cout == 4 * a.Cin && a.res != nullptr && a.w2 != nullptr &&
-           a.bias2 != nullptr && a.y2 != nullptr && a.Cout2 == a.Cin && (long)a.M * a.Cout < (1L << 30);
+           (a.Cin == 64 || a.Cin == 128) && a.Cout == 4 * a.Cin && (ds ? (a.res == nullptr && a.Cin == 64 && a.Cin2 == 64)
+                                                                       : a.res != nullptr) &&
+           a.w2 != nullptr && a.bias2 != nullptr && a.y2 != nullptr && a.Cout2 == a.Cin && (long)a.M * a.Cout < (1L << 30);
 }
 
-template <class DT, int P>
+template <class DT, int P, bool DS>
 static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
-    constexpr int XBUF = 64 * P * 2;
+    constexpr int XBUF = 64 * (P + (DS ? 64 : 0)) * 2;
     constexpr int LDS = 2 * XBUF + 8 * 32 * (32 * 4 + 16) + 64 * 4 * P * 2 + (4 * P + P) * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_c3c1_kernel<DT, P>;
+    auto kern = conv_c3c1_kernel<DT, P, DS>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -329,9 +353,11 @@ static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
 }
 
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
+    if (a.x2)
+        return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, true>(a, stream) : launch_c3c1<FP16, 64, true>(a, stream);
     if (a.Cin == 128)
-        return dtype == DIR_BF16 ? launch_c3c1<BF16, 128>(a, stream) : launch_c3c1<FP16, 128>(a, stream);
-    return dtype == DIR_BF16 ? launch_c3c1<BF16, 64>(a, stream) : launch_c3c1<FP16, 64>(a, stream);
+        return dtype == DIR_BF16 ? launch_c3c1<BF16, 128, false>(a, stream) : launch_c3c1<FP16, 128, false>(a, stream);
+    return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, false>(a, stream) : launch_c3c1<FP16, 64, false>(a, stream);
 }
 
 }  // namespace dir

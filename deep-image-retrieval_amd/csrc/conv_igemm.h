@@ -25,6 +25,10 @@ struct ConvArgs {
     const float* bias2;    // [Cout2]
     uint16_t* y2;          // NHWC [B,OH,OW,Cout2]
     int Cout2, relu2;
+    // ... and, for the first block of a stage, the block input as a second K source (the downsample conv
+    // folded into this GEMM): x2 [M][Cin2], its weights appended to w along K, its bias added to bias
+    const uint16_t* x2;
+    int Cin2;
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)

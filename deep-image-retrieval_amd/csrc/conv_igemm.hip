@@ -527,9 +527,12 @@ int conv_pick_variant(const ConvArgs& a) {
         c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     } else if (a.Cout % 256 == 0 && T >= 6) {
         // 3x3: 16 waves of 64x64; 1x1: the persistent kernel (falls through when not admissible)
-        // 1x1 without a residual (the N -> N/4 conv1 of a bottleneck, downsample): the deep-X ring
+        // 1x1 without a residual and a very long K loop (the 2048 -> 512 conv1 of layer4): the deep-X ring.
+        // A/B at batch 32 (gpurun_out/r2b): 81 -> 71 us there, but 87 -> 90 us on layer3's 1024 -> 256 -
+        // those are not short of HBM requests in flight, so they keep the 2-slot form.
         static const bool no_x3 = getenv("DIRTORCH_AMD_NO_X3") != nullptr;      // A/B and bisecting
-        c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (!a.res && !no_x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
+        const bool x3 = a.R * a.S == 1 && !a.res && !no_x3 && T >= 32;
+        c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
         // loop; with fewer than ~100 tiles even that leaves CUs idle and split-K takes over

@@ -23,6 +23,12 @@ struct ConvLayer {
     bool stem = false;    // packed as the 4x4 s1 space-to-depth form (Cin 16)
     uint16_t* d_w = nullptr;
     float* d_bias = nullptr;
+    // conv3 of a stage's first block whose downsample qualifies (conv_c3c1.hip, DS form): this conv's
+    // weights with the downsample's appended along K, and the sum of the two folded-BN biases
+    uint16_t* d_w_ds = nullptr;
+    float* d_bias_ds = nullptr;
+    std::vector<uint16_t> h_w;   // host copies, alive during finalize() only
+    std::vector<float> h_bias;
     std::map<long, int> tuned;  // M -> variant index chosen by autotune
 };
 
@@ -78,7 +84,8 @@ struct dir_engine {
     // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes
     // do not qualify and nothing was launched
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
-                 uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used);
+                 uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
+                 const uint16_t* block_in = nullptr);
     float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
                    hipStream_t stream);

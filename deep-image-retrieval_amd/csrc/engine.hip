@@ -192,6 +192,33 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_bias, L.Cout * 4));
         DIR_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), L.Cout * 4, hipMemcpyHostToDevice));
         L.tuned.clear();
+        L.h_w.swap(packed);
+        L.h_bias.swap(bias);
+    }
+    // First block of layer1 (bottleneck nets): downsample = 1x1 stride 1 over 64 channels.  Its weights
+    // are appended to conv3's along K and the biases summed, so conv_c3c1's DS form computes
+    // relu([W3 | Wds] . [t2 ; x] + b3 + bds) and the 256-wide residual tensor is never materialised.
+    for (const BlockDef& bd : blocks) {
+        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0) continue;
+        ConvLayer& c3 = convs[bd.conv3];
+        const ConvLayer& ds = convs[bd.down];
+        if (ds.stride != 1 || ds.Cin != 64 || c3.Cin != 64 || ds.Cout != c3.Cout) continue;
+        const int K3 = c3.Cin, Kd = ds.Cin, N = c3.Cout;
+        std::vector<uint16_t> cat((size_t)N * (K3 + Kd));
+        std::vector<float> bsum(N);
+        for (int o = 0; o < N; ++o) {
+            memcpy(&cat[(size_t)o * (K3 + Kd)], &c3.h_w[(size_t)o * K3], K3 * 2);
+            memcpy(&cat[(size_t)o * (K3 + Kd) + K3], &ds.h_w[(size_t)o * Kd], Kd * 2);
+            bsum[o] = c3.h_bias[o] + ds.h_bias[o];
+        }
+        DIR_HIP_CHECK(hipMalloc((void**)&c3.d_w_ds, cat.size() * 2));
+        DIR_HIP_CHECK(hipMemcpy(c3.d_w_ds, cat.data(), cat.size() * 2, hipMemcpyHostToDevice));
+        DIR_HIP_CHECK(hipMalloc((void**)&c3.d_bias_ds, N * 4));
+        DIR_HIP_CHECK(hipMemcpy(c3.d_bias_ds, bsum.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    for (ConvLayer& L : convs) {
+        std::vector<uint16_t>().swap(L.h_w);
+        std::vector<float>().swap(L.h_bias);
     }
 
     const bool fpn = desc.head == DIR_HEAD_FPN || desc.head == DIR_HEAD_FPN0;
@@ -226,8 +253,10 @@ void dir_engine::release() {
     for (ConvLayer& L : convs) {
         if (L.d_w) (void)hipFree(L.d_w);
         if (L.d_bias) (void)hipFree(L.d_bias);
-        L.d_w = nullptr;
-        L.d_bias = nullptr;
+        if (L.d_w_ds) (void)hipFree(L.d_w_ds);
+        if (L.d_bias_ds) (void)hipFree(L.d_bias_ds);
+        L.d_w = L.d_w_ds = nullptr;
+        L.d_bias = L.d_bias_ds = nullptr;
     }
     if (d_fc_w) (void)hipFree(d_fc_w);
     if (d_fc_b) (void)hipFree(d_fc_b);
@@ -409,7 +438,8 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
 
 // ---- fused bottleneck seam ----------------------------------------------------------------------------
 int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
-                         uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used) {
+                         uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
+                         const uint16_t* block_in) {
     *used = 0;
     // DIRTORCH_AMD_C3C1: "0" = never (A/B and bisecting), "force" = whenever the shapes qualify, default =
     // when every persistent workgroup gets at least ~4 pixel tiles to amortise loading both weight sets
@@ -421,6 +451,14 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.w = c3.d_w;
     a.bias = c3.d_bias;
     a.res = res;
+    if (block_in) {   // DS form: the residual is the downsample conv of the block input, folded into this GEMM
+        if (!c3.d_w_ds) return DIR_OK;
+        a.w = c3.d_w_ds;
+        a.bias = c3.d_bias_ds;
+        a.res = nullptr;
+        a.x2 = block_in;
+        a.Cin2 = 64;
+    }
     a.y = y;
     a.B = B;
     a.H = a.OH = H;
@@ -443,11 +481,12 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
         return DIR_OK;
     const bool force = mode && mode[0] == 'f';
     if (!force && (a.M + 63) / 64 < 1024) return DIR_OK;
-    const double macs = (double)a.M * ((double)c3.Cout * c3.Cin + (double)c1.Cout * c1.Cin);
-    const double bytes = 2.0 * ((double)a.M * (c3.Cin + 2.0 * c3.Cout + c1.Cout) + (double)c3.Cout * c3.Cin +
-                                (double)c1.Cout * c1.Cin);
+    const double macs = (double)a.M * ((double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
+    const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
+                                (double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
     // profile row "layerS.J.c3c1": conv3 of block J + conv1 of block J+1
-    int rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".c3c1", "conv_c3c1<" + std::to_string(c3.Cin) + ">",
+    int rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + (block_in ? ".ds+c3c1" : ".c3c1"),
+                        "conv_c3c1<" + std::to_string(c3.Cin) + (block_in ? ",ds>" : ">"),
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     hipError_t e = conv_c3c1_launch(a, dtype, stream);
@@ -532,7 +571,18 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         const bool keep = (int)bi == x4_block;
         nxt = keep ? (uint16_t*)(base + p.x4) : (cur == pp[0] ? pp[1] : pp[0]);
         const uint16_t* resid = cur;
-        if (bd.down >= 0) {
+        // layer1's first block: the downsample can ride in the seam kernel as extra K (conv_c3c1.hip, DS
+        // form) - only if that kernel will actually run for this shape, decided before anything launches
+        const bool seam_next = desc.bottleneck && bi + 1 < blocks.size() && blocks[bi + 1].down < 0 &&
+                               blocks[bi + 1].stride == 1 && !tuning;
+        bool ds_in_seam = false;
+        if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds) {
+            const char* mode = getenv("DIRTORCH_AMD_C3C1");
+            const bool off = mode && mode[0] == '0', force = mode && mode[0] == 'f';
+            const char* nods = getenv("DIRTORCH_AMD_NO_DS_SEAM");      // A/B and bisecting
+            ds_in_seam = !off && !nods && (force || ((long)B * oh * ow + 63) / 64 >= 1024);
+        }
+        if (bd.down >= 0 && !ds_in_seam) {
             rc = run_conv(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
             resid = ds;
@@ -546,11 +596,12 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             rc = run_conv(convs[bd.conv2], t1, nullptr, t2, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
             int fused = 0;
-            if (bi + 1 < blocks.size() && blocks[bi + 1].down < 0 && blocks[bi + 1].stride == 1 && !tuning) {
+            if (seam_next) {
                 // conv3 + the next block's conv1 in one kernel: the block output is not re-read (conv_c3c1.hip)
                 rc = run_seam(convs[bd.conv3], convs[blocks[bi + 1].conv1], t2, resid, nxt, t1, B, oh, ow, stream,
-                              &fused);
+                              &fused, ds_in_seam ? cur : nullptr);
                 if (rc != DIR_OK) return rc;
+                if (ds_in_seam && !fused) return fail(DIR_ERR_STATE, "seam kernel declined a downsample it was promised");
             }
             if (fused) {
                 t1_ready = true;

@@ -69,6 +69,8 @@ SIGNATURES = {
                                [c_void_p, c_size_t, POINTER(c_int), c_void_p]),
     'dir_conv_c3c1': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                       + [c_int] * 7 + [c_void_p]),
+    'dir_conv_c3c1_ds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+                         + [c_int] * 6 + [c_void_p]),
     'dir_conv_bn_act_naive': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                               + [c_int] * 13 + [c_void_p]),
     'dir_prep_input': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p,

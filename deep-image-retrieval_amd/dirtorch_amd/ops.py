@@ -103,6 +103,18 @@ def conv_c3c1(t2, w3, bias3, res, w1, bias1, relu3=True, relu1=True):
     return y, t1
 
 
+def conv_c3c1_ds(t2, x, wcat, bias, w1, bias1, relu3=True, relu1=True):
+    """Fused seam with the downsample branch folded in as extra K (dir_conv_c3c1_ds): t2, x [B,H,W,64],
+    wcat [256, 128] = [w3 | wds], bias = bias3 + bias_ds -> (y [B,H,W,256], t1 [B,H,W,64])."""
+    _need_cuda(t2, x, wcat, bias, w1, bias1)
+    B, H, W, P = t2.shape
+    y = torch.empty(B, H, W, 256, dtype=t2.dtype, device=t2.device)
+    t1 = torch.empty(B, H, W, 64, dtype=t2.dtype, device=t2.device)
+    call('dir_conv_c3c1_ds', ptr(t2), ptr(x), ptr(wcat), ptr(bias), ptr(y), ptr(w1), ptr(bias1), ptr(t1), B, H, W,
+         int(bool(relu3)), int(bool(relu1)), _dtype_code(t2), stream_ptr())
+    return y, t1
+
+
 def prep_input(img, dtype=torch.bfloat16, mean=None, std=None):
     """fp32 NCHW (normalised) or uint8 NHWC image batch -> space-to-depth NHWC16 stem input."""
     _need_cuda(img)

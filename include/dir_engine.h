@@ -170,6 +170,14 @@ int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, cons
 int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void* res, void* y, const void* w1,
                   const float* bias1, void* t1, int B, int H, int W, int P, int relu3, int relu1, int dtype,
                   void* stream);
+/* The same seam for the FIRST block of layer1 (planes 64), whose residual is the downsample branch
+ * conv1x1(x; wds [256][64]) + bn of the 64-channel block input (resnet.py:134-141, 157-160): the
+ * downsample is folded into the GEMM as 64 more K,
+ *   y = act3([w3 | wds] . [t2 ; x] + (bias3 + bias_ds)),    wcat = [256][64 + 64], bias = the sum,
+ * so the 256-wide residual tensor is never written or read.  t2, x [B,H,W,64]; y [B,H,W,256]; t1 [B,H,W,64]. */
+int dir_conv_c3c1_ds(const void* t2, const void* x, const void* wcat, const float* bias, void* y, const void* w1,
+                     const float* bias1, void* t1, int B, int H, int W, int relu3, int relu1, int dtype,
+                     void* stream);
 /* Slow, obviously-correct direct convolution with the same contract (device-side checker). */
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res,
                           void* y, int B, int H, int W, int Cin, int Cout, int R, int S,

@@ -236,8 +236,11 @@ def test_fused_seams_inside_the_network(monkeypatch):
         f_ref, d_ref, n_ref = run('0', dtype)
         f_fus, d_fus, n_fus = run('force', dtype)
         assert not any('c3c1' in k for k in n_ref.values())
-        assert n_fus.get('layer1.0.c3c1') == 'conv_c3c1<64>' and n_fus.get('layer2.1.c3c1') == 'conv_c3c1<128>', n_fus
+        # layer1's first block also folds its downsample branch into the seam kernel (DS form)
+        assert n_fus.get('layer1.0.ds+c3c1') == 'conv_c3c1<64,ds>' and n_fus.get('layer1.1.c3c1') == 'conv_c3c1<64>', n_fus
+        assert n_fus.get('layer2.1.c3c1') == 'conv_c3c1<128>', n_fus
         assert 'layer1.1.conv1' not in n_fus and 'layer1.0.conv3' not in n_fus      # replaced, not duplicated
+        assert 'layer1.0.downsample' not in n_fus and 'layer2.0.downsample' in n_fus
         assert 'layer2.0.conv1' in n_fus and 'layer1.2.conv3' in n_fus              # stage boundaries stay two kernels
         assert torch.isfinite(f_fus).all()
         rel = float((f_fus - f_ref).norm() / f_ref.norm())
@@ -245,4 +248,4 @@ def test_fused_seams_inside_the_network(monkeypatch):
         assert np.all(1 - O.cosine(d_fus.cpu().numpy(), d_ref.cpu().numpy()) < 1e-5)
     # default mode: on by itself where the map is large enough (layer1 at 512^2 x 4 = 65536 pixels)
     _, _, n_def = run('auto', 'bf16')
-    assert n_def.get('layer1.0.c3c1') == 'conv_c3c1<64>', n_def
+    assert n_def.get('layer1.0.ds+c3c1') == 'conv_c3c1<64,ds>' and n_def.get('layer1.1.c3c1') == 'conv_c3c1<64>', n_def

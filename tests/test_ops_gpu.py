@@ -563,6 +563,32 @@ def test_fused_seam_vs_oracle_and_two_kernel_path(B, H, W, P, dname, relu3):
     assert torch.equal(y, y2) and torch.equal(t1, t12)
 
 
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B,H,W', SEAM_SHAPES)
+def test_fused_seam_with_downsample_as_extra_k(B, H, W, dname):
+    """dir_conv_c3c1_ds: y = relu(conv(t2; w3) + b3 + conv(x; wds) + bds) with the downsample branch folded
+    into the GEMM (layer1's first block), then the next conv1 - against the fp32 CPU oracle of the same
+    rounded operands.  The residual is never rounded to 16 bits here (the reference's storage point the
+    un-fused path has), so the check is against the un-rounded sum."""
+    ops = _ops()
+    dt = DTYPES[dname]
+    t2 = F.relu(_rand((B, H, W, 64), 1)).to(dt)
+    x = F.relu(_rand((B, H, W, 64), 7)).to(dt)
+    w3 = _rand((256, 1, 1, 64), 2, (2.0 / 64) ** 0.5).to(dt)
+    wds = _rand((256, 1, 1, 64), 8, (2.0 / 64) ** 0.5).to(dt)
+    b3, bds = _rand((256,), 3, 0.2), _rand((256,), 9, 0.2)
+    w1 = _rand((64, 1, 1, 256), 5, (2.0 / 256) ** 0.5).to(dt)
+    b1 = _rand((64,), 6, 0.2)
+    wcat = torch.cat([w3.reshape(256, 64), wds.reshape(256, 64)], dim=1).contiguous()
+    y, t1 = ops.conv_c3c1_ds(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), w1.cuda(), b1.cuda())
+    torch.cuda.synchronize()
+    ref_y = F.relu(conv_reference(t2, w3, b3, None, 1, 0, False) + conv_reference(x, wds, bds, None, 1, 0, False))
+    check_close(y, ref_y, dname, 'ds seam: block output')
+    check_close(t1, conv_reference(y.cpu(), w1, b1, None, 1, 0, True), dname, 'ds seam: next conv1')
+    y2, t12 = ops.conv_c3c1_ds(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), w1.cuda(), b1.cuda())
+    assert torch.equal(y, y2) and torch.equal(t1, t12)
+
+
 def test_fused_seam_argument_errors():
     from dirtorch_amd import _lib
     ops = _ops()
