@@ -368,6 +368,37 @@ int dir_conv_c3c1_ds(const void* t2, const void* x, const void* wcat, const floa
     DIR_CATCH
 }
 
+int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* bias, void* y, int B, int OH, int OW,
+                  int Cin, int Cout, int Cin2, int H2, int W2, int stride2, int relu, int dtype, void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, t2, wcat, bias, nullptr, y, B, OH, OW, Cin, Cout, 1, 1, 1, 0, OH, OW, relu);
+    if (rc != DIR_OK) return rc;
+    if (!x || Cin2 <= 0 || H2 <= 0 || W2 <= 0 || stride2 <= 0) return fail(DIR_ERR_INVALID, "conv_dual: bad argument");
+    if ((OH - 1) * stride2 >= H2 || (OW - 1) * stride2 >= W2)
+        return fail(DIR_ERR_INVALID, "conv_dual: the strided pixel map leaves the second source");
+    if (Cin % 64 || Cin2 % 64) return fail(DIR_ERR_INVALID, "conv_dual: channel counts must be multiples of 64");
+    a.x2 = (const uint16_t*)x;
+    a.Cin2 = Cin2;
+    a.H2 = H2;
+    a.W2 = W2;
+    a.stride2 = stride2;
+    a.Ktot = Cin + Cin2;
+    a.T = a.Ktot / 64;
+    if (((uintptr_t)t2 & 15) || ((uintptr_t)wcat & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15))
+        return fail(DIR_ERR_INVALID, "conv_dual: tensors must be 16-byte aligned");
+    if ((long)a.M * Cout >= (1L << 30) || (long)a.M * Cin >= (1L << 30))
+        return fail(DIR_ERR_INVALID, "conv_dual: tensor exceeds 2^31 bytes; lower the batch");
+    if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv_dual: bad dtype");
+    // (small shapes included: the op-level entry point runs the form wherever the tile divides Cout)
+    int variant = -1;
+    for (int v = 0; v < conv_variant_count(); ++v)
+        if (conv_variant(v).launch_dual[0] && Cout % conv_variant(v).BN == 0) variant = v;
+    if (variant < 0) return fail(DIR_ERR_INVALID, "conv_dual: Cout must be a multiple of 256");
+    return conv_launch(a, dtype, variant, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res, void* y,
                           int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
                           int OH, int OW, int relu, int dtype, void* stream) {

@@ -29,6 +29,10 @@ struct ConvArgs {
     // folded into this GEMM): x2 [M][Cin2], its weights appended to w along K, its bias added to bias
     const uint16_t* x2;
     int Cin2;
+    // ... or (implicit-GEMM DUAL form, conv_igemm.hip) any 1x1 downsample: x2 is NHWC [B,H2,W2,Cin2], output
+    // pixel (b, oh, ow) reads x2 pixel (b, oh*stride2, ow*stride2)
+    int H2, W2, stride2;
+    uint32_t x2_bytes;
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)
@@ -49,6 +53,7 @@ struct ConvVariant {
                                // 3 = register-stationary weights 1x1 (conv_wreg.hip),
                                // 4 = kind 2 with the pixel operand three K-steps deep (conv_persist.hip, XDEEP)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
+    ConvLaunchFn launch_dual[2]; // two-source K instantiation (ConvArgs::x2: conv3 + downsample in one GEMM), or nullptr
 };
 
 bool conv1x1_persist_admissible(const ConvArgs& a);
@@ -64,6 +69,8 @@ int conv_variant_count();
 const ConvVariant& conv_variant(int i);
 bool conv_variant_admissible(int v, const ConvArgs& a);
 int conv_pick_variant(const ConvArgs& a);
+// Variant for the two-source form (a.x2 set), or -1 when none fits the shape.
+int conv_pick_dual_variant(const ConvArgs& a);
 int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream);
 // Split factor for variant `v` on problem `a` (1 = none) and the fp32 scratch it needs.
 int conv_splitk_factor(int v, const ConvArgs& a);

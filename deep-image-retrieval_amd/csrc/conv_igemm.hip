@@ -51,7 +51,12 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shr) {
 
 // SPLITK instantiations (a few small-tile variants) carry the split-K bookkeeping; the others compile
 // exactly as if it did not exist - its extra scalar state costs 8-70 VGPRs in the big tiles.
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK>
+// DUAL instantiations (two variants) take the K dimension from TWO tensors: K-steps [0, Cin/BK) from x (a flat
+// 1x1 stride-1 source: the conv3 of a bottleneck), the rest from x2 through its own descriptor and a
+// strided pixel map (the block's 1x1 downsample branch, resnet.py:134-141), against weights concatenated
+// along K.  relu([W3 | Wds] . [t2 ; x_s] + b3 + bds) is the whole tail of a stage's first block: the
+// Cout-wide residual tensor is neither written nor read, and the downsample launch disappears.
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK, bool DUAL = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvArgs a) {
     static_assert(NST >= 2 && NST <= 4, "ring depth");
     static_assert((BK == 64 || BK == 32) && (!CIN16 || BK == 64), "K-step");
@@ -147,13 +152,34 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         const int row = i * (NT / CPR) + tid / CPR;
         wvoff[i] = (uint32_t)(((tile_n * BN + row) * a.Ktot + srcchunk * 8) * 2);
     }
+    // DUAL: the second source's per-lane offsets (output pixel -> strided pixel of x2) and descriptor
+    const __amdgpu_buffer_rsrc_t rsrc_x2 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : a.x_bytes, 0x00020000);
+    uint32_t xvoff2[DUAL ? NA : 1];
+    const int T1 = DUAL ? a.Cin / BK : 0;      // K-steps served by the first source
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = i * (NT / CPR) + tid / CPR;
+            const int m = tile_m * BM + row;
+            const uint32_t mm = m < a.M ? (uint32_t)m : 0u;
+            const uint32_t b = fast_div(mm, a.div_ohw_mul, a.div_ohw_shr);
+            const uint32_t rem = mm - b * (uint32_t)(a.OH * a.OW);
+            const uint32_t oh = fast_div(rem, a.div_ow_mul, a.div_ow_shr);
+            const uint32_t ow = rem - oh * (uint32_t)a.OW;
+            const uint32_t off = (((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.Cin2 + srcchunk * 8) * 2;
+            xvoff2[DUAL ? i : 0] = m < a.M ? off : kOOB;
+        }
+    }
 
     // K-step t: filter tap `tap` (stem: filter row), byte offset `koff` of that tap/channel slice
     auto issue = [&](int t, int tap, int koff, char* stage) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             char* dst = stage + (i * NT + wave * 64) * 16;
-            if (one_tap) {
+            if (DUAL && t >= T1) {
+                dma16(rsrc_x2, dst, xvoff2[DUAL ? i : 0], (t - T1) * RB);
+            } else if (one_tap) {
                 dma16(rsrc_x, dst, xvoff[i], koff);
             } else {
                 const uint32_t v = ((xmask[i] >> tap) & 1u) ? (uint32_t)(xbase[i] + koff) : kOOB;
@@ -383,7 +409,7 @@ static void fastdiv_init(uint32_t d, uint32_t& mul, uint32_t& shr) {
     shr = p - 32;
 }
 
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK = false>
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK = false, bool DUAL = false>
 static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TN = BN / WGN / 32;
@@ -392,7 +418,7 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int EPI_BYTES = (NT / 64) * 32 * EROW;
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK>;
+    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK, DUAL>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -402,6 +428,7 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW);
+    if (DUAL) b.x2_bytes = (uint32_t)((size_t)a.B * a.H2 * a.W2 * a.Cin2 * 2);
     fastdiv_init((uint32_t)(a.OH * a.OW), b.div_ohw_mul, b.div_ohw_shr);
     fastdiv_init((uint32_t)a.OW, b.div_ow_mul, b.div_ow_shr);
     // a short K loop never touches the far slots of the ring: ask for less LDS, more residency
@@ -416,7 +443,15 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
-     {nullptr, nullptr}, 0, {nullptr, nullptr}}
+     {nullptr, nullptr}, 0, {nullptr, nullptr}, {nullptr, nullptr}}
+// ... plus the two-source K instantiation (conv3 + downsample of a stage's first block)
+#define DIR_VARIANT_DUAL(BM, BN, WGM, WGN, NST, BK, NAME)                                    \
+    {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
+     {nullptr, nullptr}, 0, {nullptr, nullptr},                                              \
+     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false, false, true>,                   \
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false, false, true>}}
 // ... plus the split-K instantiation (small-M layers)
 #define DIR_VARIANT_SK(BM, BN, WGM, WGN, NST, BK, NAME)                                      \
     {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
@@ -424,14 +459,14 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
       launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
      {nullptr, nullptr}, 0,                                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false, true>,                          \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false, true>}}
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false, true>}, {nullptr, nullptr}}
 // BN == 64 variants also carry the Cin == 16 (space-to-depth stem) instantiation.
 #define DIR_VARIANT16(BM, BN, WGM, WGN, NST, NAME)                                           \
     {NAME, BM, BN, 64 * WGM * WGN, NST, 64,                                                  \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, false>},                               \
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, 64, true>,                                 \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}, 0, {nullptr, nullptr}}
+      launch_variant<FP16, BM, BN, WGM, WGN, NST, 64, true>}, 0, {nullptr, nullptr}, {nullptr, nullptr}}
 
 // name = <pixels>x<channels>_w<waves m>x<waves n>[_s<ring depth>][_k<K-step>]
 static const ConvVariant kVariants[] = {
@@ -440,7 +475,7 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT16(256, 64, 4, 1, 2, "256x64_w4x1"),
     DIR_VARIANT(256, 128, 4, 2, 2, 64, "256x128_w4x2"),
     DIR_VARIANT(128, 256, 2, 4, 2, 64, "128x256_w2x4"),
-    DIR_VARIANT(256, 256, 4, 2, 2, 64, "256x256_w4x2"),
+    DIR_VARIANT_DUAL(256, 256, 4, 2, 2, 64, "256x256_w4x2"),
     DIR_VARIANT_SK(64, 128, 2, 2, 2, 64, "64x128_w2x2"),
     DIR_VARIANT16(64, 64, 2, 1, 2, "64x64_w2x1"),
     DIR_VARIANT(64, 128, 2, 2, 4, 64, "64x128_w2x2_s4"),
@@ -463,14 +498,14 @@ static const ConvVariant kVariants[] = {
     // pipe - the 3x3 convs of layer3/4
     DIR_VARIANT(256, 256, 4, 4, 2, 64, "256x256_w4x4"),
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
-    {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
-    {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}},
+    {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
+    {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
-    {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}},
+    {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}, {nullptr, nullptr}},
     // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
-    {"256x256_persist1x1_x3", 256, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 4, {nullptr, nullptr}},
+    {"256x256_persist1x1_x3", 256, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 4, {nullptr, nullptr}, {nullptr, nullptr}},
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
-    {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}},
+    {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}, {nullptr, nullptr}},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -562,6 +597,19 @@ int conv_pick_variant(const ConvArgs& a) {
     return last;
 }
 
+// Two-source form: which of the DUAL instantiations runs a given conv3 + downsample pair.
+int conv_pick_dual_variant(const ConvArgs& a) {
+    const bool ok = a.x2 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
+                    a.Cin % 64 == 0 && a.Cin2 % 64 == 0 && a.res == nullptr && a.ksplit <= 1;
+    if (!ok) return -1;
+    // one instantiation carries the form: 256x256, 8 waves (the two-workgroups-per-CU k32 tile goes over
+    // 128 VGPRs with the second source's offsets and loses its occupancy)
+    if (a.Cout % 256 != 0 || (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192) return -1;
+    const int v = find_variant("256x256_w4x2");
+    if (v < 0 || kVariants[v].launch_dual[0] == nullptr || a.Cout % kVariants[v].BN != 0) return -1;
+    return v;
+}
+
 // ---- split-K ---------------------------------------------------------------------------------------
 // y = act(sum_z partial[z] + bias (+ res)): the z order is fixed, so the result does not depend on
 // which workgroup finished first.  8 channels per lane.
@@ -638,6 +686,18 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
         ((uintptr_t)a.res & 15) || ((uintptr_t)a.bias & 15))
         return fail(DIR_ERR_INVALID, "conv: tensors must be 16-byte aligned");
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv: bad dtype");
+    if (a.x2) {   // two-source K: conv3 + downsample in one GEMM
+        if (variant < 0) variant = conv_pick_dual_variant(a);
+        if (variant < 0 || variant >= kNumVariants || kVariants[variant].launch_dual[0] == nullptr ||
+            a.Cout % kVariants[variant].BN != 0 || a.R != 1 || a.S != 1 || a.stride != 1 || a.res || a.ksplit > 1 ||
+            a.Cin2 % 64 != 0 || a.Ktot != a.Cin + a.Cin2 || ((uintptr_t)a.x2 & 15) ||
+            (long)a.B * a.H2 * a.W2 * a.Cin2 >= (1L << 30))
+            return fail(DIR_ERR_INVALID, "conv: no two-source form for this shape / variant");
+        hipError_t e = kVariants[variant].launch_dual[dtype](a, stream);
+        if (e != hipSuccess)
+            return fail(DIR_ERR_HIP, std::string("conv launch ") + kVariants[variant].name + "/dual: " + hipGetErrorString(e));
+        return DIR_OK;
+    }
     if (variant < 0) variant = conv_pick_variant(a);
     if (!conv_variant_admissible(variant, a))
         return fail(DIR_ERR_INVALID, "conv: variant not admissible for this shape");

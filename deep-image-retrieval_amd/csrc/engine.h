@@ -86,6 +86,10 @@ struct dir_engine {
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
                  uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
                  const uint16_t* block_in = nullptr);
+    // conv3 + the block's 1x1 downsample branch as ONE two-source GEMM (conv_igemm.hip DUAL form); dry = only
+    // report whether it would run (decided before the downsample would be launched)
+    int run_conv_dual(dir::ConvLayer& c3, const dir::ConvLayer& ds, const uint16_t* t2, const uint16_t* xin,
+                      uint16_t* y, int B, int Hin, int Win, int OH, int OW, hipStream_t stream, int* used, bool dry);
     float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
                    hipStream_t stream);

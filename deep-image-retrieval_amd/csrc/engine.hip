@@ -195,14 +195,16 @@ int dir_engine::finalize(int dt) {
         L.h_w.swap(packed);
         L.h_bias.swap(bias);
     }
-    // First block of layer1 (bottleneck nets): downsample = 1x1 stride 1 over 64 channels.  Its weights
-    // are appended to conv3's along K and the biases summed, so conv_c3c1's DS form computes
-    // relu([W3 | Wds] . [t2 ; x] + b3 + bds) and the 256-wide residual tensor is never materialised.
+    // First block of every stage (bottleneck nets): the residual is a 1x1 downsample conv of the block
+    // input.  Its weights are appended to conv3's along K and the biases summed, so that
+    // relu([W3 | Wds] . [t2 ; x_s] + b3 + bds) is ONE GEMM and the Cout-wide residual tensor is never
+    // materialised: conv_c3c1's DS form (layer1: 64 + 64 channels, stride 1) or the two-source form of the
+    // implicit-GEMM kernel (layers 2-4, stride 2).
     for (const BlockDef& bd : blocks) {
         if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0) continue;
         ConvLayer& c3 = convs[bd.conv3];
         const ConvLayer& ds = convs[bd.down];
-        if (ds.stride != 1 || ds.Cin != 64 || c3.Cin != 64 || ds.Cout != c3.Cout) continue;
+        if (ds.R != 1 || ds.S != 1 || ds.pad != 0 || ds.Cout != c3.Cout || ds.Cin % 64 != 0 || c3.Cin % 64 != 0) continue;
         const int K3 = c3.Cin, Kd = ds.Cin, N = c3.Cout;
         std::vector<uint16_t> cat((size_t)N * (K3 + Kd));
         std::vector<float> bsum(N);
@@ -452,7 +454,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.bias = c3.d_bias;
     a.res = res;
     if (block_in) {   // DS form: the residual is the downsample conv of the block input, folded into this GEMM
-        if (!c3.d_w_ds) return DIR_OK;
+        if (!c3.d_w_ds || c3.Cin != 64) return DIR_OK;
         a.w = c3.d_w_ds;
         a.bias = c3.d_bias_ds;
         a.res = nullptr;
@@ -492,6 +494,48 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     hipError_t e = conv_c3c1_launch(a, dtype, stream);
     if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv_c3c1 launch: ") + hipGetErrorString(e));
     *used = 1;
+    return prof_end(stream);
+}
+
+// ---- conv3 + downsample as one two-source GEMM ------------------------------------------------------------
+int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t* t2, const uint16_t* xin,
+                              uint16_t* y, int B, int Hin, int Win, int OH, int OW, hipStream_t stream, int* used,
+                              bool dry) {
+    *used = 0;
+    if (!c3.d_w_ds || getenv("DIRTORCH_AMD_NO_DUAL")) return DIR_OK;      // (env: A/B and bisecting)
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = t2;
+    a.w = c3.d_w_ds;
+    a.bias = c3.d_bias_ds;
+    a.y = y;
+    a.B = B;
+    a.H = a.OH = OH;
+    a.W = a.OW = OW;
+    a.Cin = c3.Cin;
+    a.Cout = c3.Cout;
+    a.R = a.S = 1;
+    a.stride = 1;
+    a.relu = c3.relu ? 1 : 0;
+    a.M = B * OH * OW;
+    a.x2 = xin;
+    a.Cin2 = ds.Cin;
+    a.H2 = Hin;
+    a.W2 = Win;
+    a.stride2 = ds.stride;
+    a.Ktot = a.Cin + a.Cin2;
+    a.T = a.Ktot / 64;
+    const int variant = conv_pick_dual_variant(a);
+    if (variant < 0) return DIR_OK;
+    *used = 1;
+    if (dry) return DIR_OK;
+    const double macs = (double)a.M * c3.Cout * (double)a.Ktot;
+    const double bytes = 2.0 * ((double)a.M * (c3.Cin + ds.Cin + c3.Cout) + (double)c3.Cout * a.Ktot);
+    int rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".ds+conv3",
+                        std::string("conv_igemm<") + conv_variant(variant).name + "/dual>", 2.0 * macs, bytes, stream);
+    if (rc != DIR_OK) return rc;
+    rc = conv_launch(a, dtype, variant, stream);
+    if (rc != DIR_OK) return rc;
     return prof_end(stream);
 }
 
@@ -582,7 +626,13 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             const char* nods = getenv("DIRTORCH_AMD_NO_DS_SEAM");      // A/B and bisecting
             ds_in_seam = !off && !nods && (force || ((long)B * oh * ow + 63) / 64 >= 1024);
         }
-        if (bd.down >= 0 && !ds_in_seam) {
+        // the other stages' first blocks: conv3 + downsample as one two-source GEMM (conv_igemm.hip, DUAL)
+        int ds_dual = 0;
+        if (bd.down >= 0 && !ds_in_seam && desc.bottleneck && !tuning) {
+            rc = run_conv_dual(convs[bd.conv3], convs[bd.down], t2, cur, nxt, B, h, w, oh, ow, stream, &ds_dual, true);
+            if (rc != DIR_OK) return rc;
+        }
+        if (bd.down >= 0 && !ds_in_seam && !ds_dual) {
             rc = run_conv(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
             resid = ds;
@@ -596,16 +646,21 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             rc = run_conv(convs[bd.conv2], t1, nullptr, t2, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
             int fused = 0;
-            if (seam_next) {
+            if (ds_dual) {
+                rc = run_conv_dual(convs[bd.conv3], convs[bd.down], t2, cur, nxt, B, h, w, oh, ow, stream, &fused, false);
+                if (rc != DIR_OK) return rc;
+                if (!fused) return fail(DIR_ERR_STATE, "two-source conv declined a downsample it was promised");
+                fused = 2;   // block output written; the next block's conv1 still has to run
+            } else if (seam_next) {
                 // conv3 + the next block's conv1 in one kernel: the block output is not re-read (conv_c3c1.hip)
                 rc = run_seam(convs[bd.conv3], convs[blocks[bi + 1].conv1], t2, resid, nxt, t1, B, oh, ow, stream,
                               &fused, ds_in_seam ? cur : nullptr);
                 if (rc != DIR_OK) return rc;
                 if (ds_in_seam && !fused) return fail(DIR_ERR_STATE, "seam kernel declined a downsample it was promised");
             }
-            if (fused) {
+            if (fused == 1) {
                 t1_ready = true;
-            } else {
+            } else if (!fused) {
                 rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
                 if (rc != DIR_OK) return rc;
             }

@@ -71,6 +71,7 @@ SIGNATURES = {
                       + [c_int] * 7 + [c_void_p]),
     'dir_conv_c3c1_ds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                          + [c_int] * 6 + [c_void_p]),
+    'dir_conv_dual': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     'dir_conv_bn_act_naive': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                               + [c_int] * 13 + [c_void_p]),
     'dir_prep_input': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p,

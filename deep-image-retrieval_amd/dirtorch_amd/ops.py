@@ -115,6 +115,19 @@ def conv_c3c1_ds(t2, x, wcat, bias, w1, bias1, relu3=True, relu1=True):
     return y, t1
 
 
+def conv_dual(t2, x, wcat, bias, stride2=2, relu=True):
+    """conv3 + downsample as one two-source GEMM (dir_conv_dual): t2 [B,OH,OW,Cin], x [B,H2,W2,Cin2],
+    wcat [Cout, Cin + Cin2], bias fp32 [Cout] -> y [B,OH,OW,Cout]."""
+    _need_cuda(t2, x, wcat, bias)
+    B, OH, OW, Cin = t2.shape
+    _, H2, W2, Cin2 = x.shape
+    Cout = wcat.shape[0]
+    y = torch.empty(B, OH, OW, Cout, dtype=t2.dtype, device=t2.device)
+    call('dir_conv_dual', ptr(t2), ptr(x), ptr(wcat), ptr(bias), ptr(y), B, OH, OW, Cin, Cout, Cin2, H2, W2,
+         int(stride2), int(bool(relu)), _dtype_code(t2), stream_ptr())
+    return y
+
+
 def prep_input(img, dtype=torch.bfloat16, mean=None, std=None):
     """fp32 NCHW (normalised) or uint8 NHWC image batch -> space-to-depth NHWC16 stem input."""
     _need_cuda(img)

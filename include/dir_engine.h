@@ -170,6 +170,13 @@ int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, cons
 int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void* res, void* y, const void* w1,
                   const float* bias1, void* t1, int B, int H, int W, int P, int relu3, int relu1, int dtype,
                   void* stream);
+/* conv3 + bn3 + the block's downsample branch + add + ReLU of a stage's FIRST bottleneck as one GEMM over
+ * two K sources (csrc/conv_igemm.hip, DUAL form; dirtorch/nets/backbones/resnet.py:78-85 with :134-141):
+ *   y[b,oh,ow,:] = act([w3 | wds] . [t2[b,oh,ow,:] ; x[b,oh*stride2,ow*stride2,:]] + bias),  bias = bias3 + bias_ds
+ * t2 [B,OH,OW,Cin], x [B,H2,W2,Cin2] NHWC 16-bit, wcat [Cout][Cin + Cin2], Cout % 256 == 0, Cin, Cin2 % 64 == 0.
+ * The Cout-wide residual tensor is neither written nor read. */
+int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* bias, void* y, int B, int OH, int OW,
+                  int Cin, int Cout, int Cin2, int H2, int W2, int stride2, int relu, int dtype, void* stream);
 /* The same seam for the FIRST block of layer1 (planes 64), whose residual is the downsample branch
  * conv1x1(x; wds [256][64]) + bn of the 64-channel block input (resnet.py:134-141, 157-160): the
  * downsample is folded into the GEMM as 64 more K,

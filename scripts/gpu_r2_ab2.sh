@@ -1,0 +1,28 @@
+#!/bin/bash
+# DS-seam tests + A/B
+cd "$GRAFT_REPO_ROOT"
+TAG=${1:-r2c}
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q -s -p no:cacheprovider -k "seam or deep_x or golden or trunk_features" > $O/pytest_new.log 2>&1
+echo "pytest(new) rc=$?" | tee $O/pytest_new.rc
+grep -a " passed\| failed\|^FAILED\|^ERROR\|Error\|bad elements" $O/pytest_new.log | tail -20
+run() {
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --layers > $O/bench_$name.json 2> $O/layers_$name.txt
+  echo "$name rc=$? $(python - <<PY
+import json
+try:
+    d=json.loads(open('$O/bench_$name.json').read().strip().splitlines()[-1])
+    print(d['value'], 'img/s', d['ms_per_step'], 'ms/step')
+except Exception as e:
+    print('no result', e)
+PY
+)"
+}
+run nods DIRTORCH_AMD_NO_DS_SEAM=1
+run ds DIRTORCH_AMD_X=1
+run nods2 DIRTORCH_AMD_NO_DS_SEAM=1
+run ds2 DIRTORCH_AMD_X=1
+grep -a "layer1.0\|layer4.1.conv1" $O/layers_nods.txt $O/layers_ds.txt | cut -c1-150

@@ -214,17 +214,25 @@ def test_register_stationary_conv3_inside_the_network():
 
 
 def test_fused_seams_inside_the_network(monkeypatch):
-    """ResNet-50 at 4 x 512^2: layer1 (128^2 maps, 65536 pixels) and - forced - layer2 run their
-    conv3 -> next-conv1 seams through conv_c3c1.hip.  The feature map must equal the un-fused network's
-    up to 16-bit rounding flips (the fused kernel feeds conv1 the same rounded tensor it stores), and the
-    profile must show the fused launches."""
+    """ResNet-50 at 8 x 1024^2 with and without the fused kernels of the bottleneck tails:
+      * conv_c3c1.hip: conv3 (+ residual + ReLU) -> next block's conv1 in layer1 / layer2, the DS form for
+        layer1's first block (downsample folded in as extra K);
+      * conv_igemm.hip DUAL: conv3 + downsample of the first block of layers 2-4 as one two-source GEMM.
+    The feature map must equal the un-fused network's up to 16-bit rounding flips (the fused kernels feed
+    conv1 the same rounded tensor they store; the folded downsample skips one rounding of the residual),
+    and the profile must show the fused launches in place of the ones they replace."""
     import dir_oracle as O
     sd = O.synth_state_dict('resnet50', seed=7)
     g = torch.Generator(device='cuda').manual_seed(3)
-    x = torch.randint(0, 256, (4, 512, 512, 3), generator=g, dtype=torch.uint8, device='cuda')
+    x = torch.randint(0, 256, (8, 1024, 1024, 3), generator=g, dtype=torch.uint8, device='cuda')
 
-    def run(mode, dtype):
-        monkeypatch.setenv('DIRTORCH_AMD_C3C1', mode)
+    def run(fused, dtype):
+        if fused:
+            monkeypatch.delenv('DIRTORCH_AMD_C3C1', raising=False)
+            monkeypatch.delenv('DIRTORCH_AMD_NO_DUAL', raising=False)
+        else:
+            monkeypatch.setenv('DIRTORCH_AMD_C3C1', '0')
+            monkeypatch.setenv('DIRTORCH_AMD_NO_DUAL', '1')
         net = make_net('resnet50', {}, sd, dtype)
         f = net.forward_features(x).float()
         net.set_profiling(True)
@@ -233,19 +241,33 @@ def test_fused_seams_inside_the_network(monkeypatch):
         return f, d, names
 
     for dtype, tol in (('bf16', 8e-3), ('fp16', 1e-3)):
-        f_ref, d_ref, n_ref = run('0', dtype)
-        f_fus, d_fus, n_fus = run('force', dtype)
-        assert not any('c3c1' in k for k in n_ref.values())
-        # layer1's first block also folds its downsample branch into the seam kernel (DS form)
+        f_ref, d_ref, n_ref = run(False, dtype)
+        f_fus, d_fus, n_fus = run(True, dtype)
+        assert not any('c3c1' in k or 'dual' in k for k in n_ref.values())
+        assert 'layer1.0.downsample' in n_ref and 'layer2.0.downsample' in n_ref
         assert n_fus.get('layer1.0.ds+c3c1') == 'conv_c3c1<64,ds>' and n_fus.get('layer1.1.c3c1') == 'conv_c3c1<64>', n_fus
         assert n_fus.get('layer2.1.c3c1') == 'conv_c3c1<128>', n_fus
-        assert 'layer1.1.conv1' not in n_fus and 'layer1.0.conv3' not in n_fus      # replaced, not duplicated
-        assert 'layer1.0.downsample' not in n_fus and 'layer2.0.downsample' in n_fus
-        assert 'layer2.0.conv1' in n_fus and 'layer1.2.conv3' in n_fus              # stage boundaries stay two kernels
+        for s in (2, 3, 4):
+            assert n_fus.get('layer%d.0.ds+conv3' % s) == 'conv_igemm<256x256_w4x2/dual>', n_fus
+            assert 'layer%d.0.downsample' % s not in n_fus and 'layer%d.0.conv3' % s not in n_fus
+        assert 'layer1.1.conv1' not in n_fus and 'layer1.0.conv3' not in n_fus and 'layer1.0.downsample' not in n_fus
+        assert 'layer2.0.conv1' in n_fus and 'layer1.2.conv3' in n_fus and 'layer2.1.conv1' in n_fus   # stage boundaries
         assert torch.isfinite(f_fus).all()
         rel = float((f_fus - f_ref).norm() / f_ref.norm())
         assert rel < tol, (dtype, rel)
         assert np.all(1 - O.cosine(d_fus.cpu().numpy(), d_ref.cpu().numpy()) < 1e-5)
-    # default mode: on by itself where the map is large enough (layer1 at 512^2 x 4 = 65536 pixels)
-    _, _, n_def = run('auto', 'bf16')
-    assert n_def.get('layer1.0.ds+c3c1') == 'conv_c3c1<64,ds>' and n_def.get('layer1.1.c3c1') == 'conv_c3c1<64>', n_def
+    # small maps: the fused forms step aside (too few tiles per persistent workgroup / per chip)
+    net = make_net('resnet50', {}, sd, 'bf16')
+    net.set_profiling(True)
+    net(x[:1, :256, :256].contiguous())
+    small = {r['name']: r['kernel'] for r in net.get_profile()}
+    assert not any('c3c1' in k or 'dual' in k for k in small.values()), small
+    monkeypatch.setenv('DIRTORCH_AMD_C3C1', 'force')
+    net = make_net('resnet50', {}, sd, 'bf16')
+    net.set_profiling(True)
+    d_forced = net(x[:2, :256, :256].contiguous())
+    forced = {r['name']: r['kernel'] for r in net.get_profile()}
+    assert forced.get('layer1.0.ds+c3c1') == 'conv_c3c1<64,ds>' and forced.get('layer2.2.c3c1') == 'conv_c3c1<128>'
+    monkeypatch.setenv('DIRTORCH_AMD_C3C1', '0')
+    d_plain = make_net('resnet50', {}, sd, 'bf16')(x[:2, :256, :256].contiguous())
+    assert np.all(1 - O.cosine(d_forced.cpu().numpy(), d_plain.cpu().numpy()) < 1e-5)

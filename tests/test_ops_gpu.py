@@ -589,6 +589,35 @@ def test_fused_seam_with_downsample_as_extra_k(B, H, W, dname):
     assert torch.equal(y, y2) and torch.equal(t1, t12)
 
 
+# (B, OH, OW, Cin, Cout, Cin2, stride2): layer2.0 / layer3.0 / layer4.0 shapes in small, odd maps, and stride 1
+DUAL_SHAPES = [(2, 13, 11, 128, 512, 256, 2), (1, 9, 17, 256, 1024, 512, 2), (1, 7, 5, 512, 2048, 1024, 2),
+               (3, 20, 20, 64, 256, 64, 1)]
+
+
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B,OH,OW,Cin,Cout,Cin2,s2', DUAL_SHAPES)
+def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2, s2, dname):
+    """dir_conv_dual: relu(conv1x1(t2; w3) + b3 + conv1x1_stride(x; wds) + bds) as one GEMM whose K runs over
+    two tensors, against the fp32 CPU oracle of the two convolutions on the same rounded operands (odd input
+    sizes: the strided pixel map, ragged last tile)."""
+    ops = _ops()
+    dt = DTYPES[dname]
+    H2, W2 = (OH - 1) * s2 + 1 + (s2 - 1), (OW - 1) * s2 + 1      # odd / even input sizes that map to OH x OW
+    t2 = F.relu(_rand((B, OH, OW, Cin), 1)).to(dt)
+    x = F.relu(_rand((B, H2, W2, Cin2), 7)).to(dt)
+    w3 = _rand((Cout, 1, 1, Cin), 2, (2.0 / Cin) ** 0.5).to(dt)
+    wds = _rand((Cout, 1, 1, Cin2), 8, (2.0 / Cin2) ** 0.5).to(dt)
+    b3, bds = _rand((Cout,), 3, 0.2), _rand((Cout,), 9, 0.2)
+    wcat = torch.cat([w3.reshape(Cout, Cin), wds.reshape(Cout, Cin2)], dim=1).contiguous()
+    y = ops.conv_dual(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), stride2=s2, relu=True)
+    torch.cuda.synchronize()
+    ds = conv_reference(x, wds, bds, None, s2, 0, False)
+    assert ds.shape[1:3] == (OH, OW)
+    ref = F.relu(conv_reference(t2, w3, b3, None, 1, 0, False) + ds)
+    check_close(y, ref, dname, 'two-source conv3 + downsample')
+    assert torch.equal(y, ops.conv_dual(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), stride2=s2, relu=True))
+
+
 def test_fused_seam_argument_errors():
     from dirtorch_amd import _lib
     ops = _ops()
