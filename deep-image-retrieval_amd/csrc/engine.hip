@@ -454,7 +454,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.bias = c3.d_bias;
     a.res = res;
     if (block_in) {   // DS form: the residual is the downsample conv of the block input, folded into this GEMM
-        if (!c3.d_w_ds || c3.Cin != 64) return DIR_OK;
+        if (!c3.d_w_ds || c3.Cin != 64) return DIR_OK;   // (the caller checks the downsample's own shape)
         a.w = c3.d_w_ds;
         a.bias = c3.d_bias_ds;
         a.res = nullptr;
@@ -620,7 +620,8 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         const bool seam_next = desc.bottleneck && bi + 1 < blocks.size() && blocks[bi + 1].down < 0 &&
                                blocks[bi + 1].stride == 1 && !tuning;
         bool ds_in_seam = false;
-        if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds) {
+        if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds && convs[bd.conv3].Cin == 64 &&
+            convs[bd.down].Cin == 64 && convs[bd.down].stride == 1) {
             const char* mode = getenv("DIRTORCH_AMD_C3C1");
             const bool off = mode && mode[0] == '0', force = mode && mode[0] == 'f';
             const char* nods = getenv("DIRTORCH_AMD_NO_DS_SEAM");      // A/B and bisecting
