@@ -319,7 +319,7 @@ int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, cons
 }
 
 int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void* res, void* y, const void* w1,
-                  const float* bias1, void* t1, int B, int H, int W, int P, int relu3, int relu1, int dtype,
+                  const float* bias1, void* t1, int B, int H, int W, int P, int P2, int relu3, int relu1, int dtype,
                   void* stream) {
     DIR_TRY
     ConvArgs a;
@@ -330,9 +330,10 @@ int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void
     a.w2 = (const uint16_t*)w1;
     a.bias2 = bias1;
     a.y2 = (uint16_t*)t1;
-    a.Cout2 = P;
+    a.Cout2 = P2;
     a.relu2 = relu1 ? 1 : 0;
-    if (!conv_c3c1_admissible(a)) return fail(DIR_ERR_INVALID, "conv_c3c1: planes must be 64 or 128");
+    if (!conv_c3c1_admissible(a))
+        return fail(DIR_ERR_INVALID, "conv_c3c1: planes must be 64 or 128, and P2 = P (or 128 after 64)");
     if (((uintptr_t)t2 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)res & 15) || ((uintptr_t)y & 15) ||
         ((uintptr_t)w1 & 15) || ((uintptr_t)t1 & 15) || ((uintptr_t)bias3 & 15) || ((uintptr_t)bias1 & 15))
         return fail(DIR_ERR_INVALID, "conv_c3c1: tensors must be 16-byte aligned");

@@ -35,10 +35,13 @@ namespace dir {
 
 static constexpr uint32_t kOOBf = 0x80000000u;
 
-template <class DT, int P, bool DS>
+// P2 = planes of the block that conv1' opens: P inside a stage, 2 P across the layer1 -> layer2 boundary
+// (layer2's first conv1 is 1x1 stride 1 over the 256-wide layer1 output; the stride sits in its conv2).
+template <class DT, int P, bool DS, int P2>
 __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     static_assert(P == 64 || P == 128, "planes");
-    static_assert(!DS || P == 64, "the downsample form is layer1's: 64 + 64 input channels");
+    static_assert(P2 == P || (P == 64 && P2 == 128), "conv1' width");
+    static_assert(!DS || (P == 64 && P2 == 64), "the downsample form is layer1's: 64 + 64 input channels");
     constexpr int KA = P + (DS ? 64 : 0);       // phase A contraction length (t2 channels [+ block input])
     constexpr int C4 = 4 * P;                   // block width
     constexpr int BM = 64, NT = 512;
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     constexpr int EPI_OFF = 2 * XBUF;
     constexpr int OUT_OFF = EPI_OFF + 8 * 32 * EROW;
     constexpr int OUTB = BM * C4 * 2;           // the out-tile: C4/64 blocks of [64 px][128 B]
-    constexpr int BIAS_OFF = OUT_OFF + OUTB;    // bias3 [C4] then bias1 [P], fp32
+    constexpr int BIAS_OFF = OUT_OFF + OUTB;    // bias3 [C4] then bias1 [P2], fp32
     constexpr int KSB = (C4 / 2) / 16;          // phase B k-slices per K half (8 / 16)
     typedef typename DT::frag_t frag_t;
     static_assert(NX >= 1 && XBUF % (16 * NT) == 0, "tile split");
@@ -67,7 +70,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc_x2 =      // DS: the block input [M][64]
         __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? a.x2 : a.x), 0, DS ? (uint32_t)((size_t)a.M * 128) : a.x_bytes, 0x00020000);
     const uint32_t y_bytes = (uint32_t)((size_t)a.M * C4 * 2);
-    const uint32_t y2_bytes = (uint32_t)((size_t)a.M * P * 2);
+    const uint32_t y2_bytes = (uint32_t)((size_t)a.M * P2 * 2);
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.y2, 0, y2_bytes, 0x00020000);
@@ -85,11 +88,12 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KSA; ++ks)
             w3[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + i * 32 + lrow) * KA + ks * 16 + 8 * lhi);
-    // phase B roles: P = 128: (n-tile = w & 3, K half = w >> 2), both 32-pixel strips;
-    //                P =  64: (n-tile = w & 1, strip = (w >> 1) & 1, K half = w >> 2)
-    const int nt = P == 128 ? (wave & 3) : (wave & 1);
+    // phase B roles: P2 = 128: (n-tile = w & 3, K half = w >> 2), both 32-pixel strips;
+    //                P2 =  64: (n-tile = w & 1, strip = (w >> 1) & 1, K half = w >> 2)
+    constexpr bool WIDE = P2 == 128;
+    const int nt = WIDE ? (wave & 3) : (wave & 1);
     const int kh = wave >> 2;
-    const int jb = P == 128 ? 0 : ((wave >> 1) & 1);
+    const int jb = WIDE ? 0 : ((wave >> 1) & 1);
     frag_t w1[KSB];
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks)
@@ -111,7 +115,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     float* const sbias3 = (float*)(smem + BIAS_OFF);
     float* const sbias1 = sbias3 + C4;
     for (int i = tid; i < C4; i += NT) sbias3[i] = a.bias[i];
-    if (tid < P) sbias1[tid] = a.bias2[tid];
+    if (tid < P2) sbias1[tid] = a.bias2[tid];
     char* const ebase = smem + EPI_OFF + wave * (32 * EROW);              // this wave's staging rows
     char* const pbase = smem + EPI_OFF + (wave ^ 4) * (32 * EROW);        // the K-half partner's
     char* const otile = smem + OUT_OFF;
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
 
         // ================= phase B: t1' = relu(out . W1^T + bias1) ======================================
         {
-            constexpr int NJ = P == 128 ? 2 : 1;    // strips this wave multiplies
+            constexpr int NJ = WIDE ? 2 : 1;    // strips this wave multiplies
             f32x16_t acc1[NJ];
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj)
@@ -246,28 +250,28 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
                 const int kb = kh * (C4 / 128) + (ks >> 2);
 #pragma unroll
                 for (int jj = 0; jj < NJ; ++jj) {
-                    const int j = P == 128 ? jj : jb;
+                    const int j = WIDE ? jj : jb;
                     const frag_t of = *(const frag_t*)(otile + kb * (BM * 128) + j * (32 * 128) + lbase +
                                                        (((2 * (ks & 3) + lhi) ^ lswz) << 4));
                     acc1[jj] = DT::mfma32(w1[ks], of, acc1[jj]);
                 }
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            // K halves meet in fp32: P = 128: wave (nt, kh) finishes strip kh and hands its partial of the
-            // other strip to its partner (w ^ 4); P = 64: the kh = 1 wave hands over, kh = 0 finishes.
-            const int give = P == 128 ? (1 - kh) : 0;
-            const bool gives = P == 128 || kh == 1;
-            const bool finishes = P == 128 || kh == 0;
+            // K halves meet in fp32: P2 = 128: wave (nt, kh) finishes strip kh and hands its partial of the
+            // other strip to its partner (w ^ 4); P2 = 64: the kh = 1 wave hands over, kh = 0 finishes.
+            const int give = WIDE ? (1 - kh) : 0;
+            const bool gives = WIDE || kh == 1;
+            const bool finishes = WIDE || kh == 0;
             if (gives) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x16_t& s = acc1[P == 128 ? give : 0];
+                    const f32x16_t& s = acc1[WIDE ? give : 0];
                     const f32x4_t v = {s[4 * g + 0], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
                     *(f32x4_t*)(ebase + lrow * EROW + (8 * g + 4 * lhi) * 4) = v;
                 }
             }
             __syncthreads();   // (2) partials visible
-            f32x16_t sum = acc1[P == 128 ? kh : 0];
+            f32x16_t sum = acc1[WIDE ? kh : 0];
             if (finishes) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
             }
             __syncthreads();   // (3) partner done reading before the areas are reused
             if (finishes) {
-                const int j = P == 128 ? kh : jb;
+                const int j = WIDE ? kh : jb;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4_t v = {sum[4 * g + 0], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]};
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                     const int m = m0 + j * 32 + mrow;
-                    const uint32_t off = m < a.M ? (uint32_t)m * (uint32_t)(P * 2) + (uint32_t)((nt * 32 + ecol) * 2) : kOOBf;
+                    const uint32_t off = m < a.M ? (uint32_t)m * (uint32_t)(P2 * 2) + (uint32_t)((nt * 32 + ecol) * 2) : kOOBf;
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y2, off, 0, 0);
                 }
             }
@@ -327,15 +331,16 @@ bool conv_c3c1_admissible(const ConvArgs& a) {
     return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
            (a.Cin == 64 || a.Cin == 128) && a.Cout == 4 * a.Cin && (ds ? (a.res == nullptr && a.Cin == 64 && a.Cin2 == 64)
                                                                        : a.res != nullptr) &&
-           a.w2 != nullptr && a.bias2 != nullptr && a.y2 != nullptr && a.Cout2 == a.Cin && (long)a.M * a.Cout < (1L << 30);
+           a.w2 != nullptr && a.bias2 != nullptr && a.y2 != nullptr &&
+           (a.Cout2 == a.Cin || (!ds && a.Cin == 64 && a.Cout2 == 128)) && (long)a.M * a.Cout < (1L << 30);
 }
 
-template <class DT, int P, bool DS>
+template <class DT, int P, bool DS, int P2 = P>
 static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
     constexpr int XBUF = 64 * (P + (DS ? 64 : 0)) * 2;
-    constexpr int LDS = 2 * XBUF + 8 * 32 * (32 * 4 + 16) + 64 * 4 * P * 2 + (4 * P + P) * 4;
+    constexpr int LDS = 2 * XBUF + 8 * 32 * (32 * 4 + 16) + 64 * 4 * P * 2 + (4 * P + P2) * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_c3c1_kernel<DT, P, DS>;
+    auto kern = conv_c3c1_kernel<DT, P, DS, P2>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -357,6 +362,8 @@ hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
         return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, true>(a, stream) : launch_c3c1<FP16, 64, true>(a, stream);
     if (a.Cin == 128)
         return dtype == DIR_BF16 ? launch_c3c1<BF16, 128, false>(a, stream) : launch_c3c1<FP16, 128, false>(a, stream);
+    if (a.Cout2 == 128)   // layer1 -> layer2
+        return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, false, 128>(a, stream) : launch_c3c1<FP16, 64, false, 128>(a, stream);
     return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, false>(a, stream) : launch_c3c1<FP16, 64, false>(a, stream);
 }
 

@@ -617,8 +617,9 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         const uint16_t* resid = cur;
         // layer1's first block: the downsample can ride in the seam kernel as extra K (conv_c3c1.hip, DS
         // form) - only if that kernel will actually run for this shape, decided before anything launches
-        const bool seam_next = desc.bottleneck && bi + 1 < blocks.size() && blocks[bi + 1].down < 0 &&
-                               blocks[bi + 1].stride == 1 && !tuning;
+        // (the next block's conv1 is 1x1 stride 1 even across a stage boundary - the stride sits in conv2 -
+        // so the seam kernel also serves layer1 -> layer2; run_seam checks the widths it can hold)
+        const bool seam_next = desc.bottleneck && bi + 1 < blocks.size() && !tuning;
         bool ds_in_seam = false;
         if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds && convs[bd.conv3].Cin == 64 &&
             convs[bd.down].Cin == 64 && convs[bd.down].stride == 1) {

@@ -68,7 +68,7 @@ SIGNATURES = {
     'dir_conv_bn_act_splitk': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 15 +
                                [c_void_p, c_size_t, POINTER(c_int), c_void_p]),
     'dir_conv_c3c1': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
-                      + [c_int] * 7 + [c_void_p]),
+                      + [c_int] * 8 + [c_void_p]),
     'dir_conv_c3c1_ds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                          + [c_int] * 6 + [c_void_p]),
     'dir_conv_dual': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),

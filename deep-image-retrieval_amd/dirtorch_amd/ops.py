@@ -92,13 +92,14 @@ def conv_bn_act(x, w, bias, res=None, stride=1, pad=0, relu=True, out_hw=None, v
 
 
 def conv_c3c1(t2, w3, bias3, res, w1, bias1, relu3=True, relu1=True):
-    """Fused bottleneck seam (dir_conv_c3c1): returns (y [B,H,W,4P], t1 [B,H,W,P]).
-    t2 [B,H,W,P], w3 [4P,1,1,P] or [4P,P], res [B,H,W,4P], w1 [P,1,1,4P] or [P,4P]; 16-bit NHWC, fp32 biases."""
+    """Fused bottleneck seam (dir_conv_c3c1): returns (y [B,H,W,4P], t1 [B,H,W,P2]).
+    t2 [B,H,W,P], w3 [4P,1,1,P] or [4P,P], res [B,H,W,4P], w1 [P2,1,1,4P] or [P2,4P]; 16-bit NHWC, fp32 biases."""
     _need_cuda(t2, w3, bias3, res, w1, bias1)
     B, H, W, P = t2.shape
+    P2 = w1.shape[0]
     y = torch.empty(B, H, W, 4 * P, dtype=t2.dtype, device=t2.device)
-    t1 = torch.empty(B, H, W, P, dtype=t2.dtype, device=t2.device)
-    call('dir_conv_c3c1', ptr(t2), ptr(w3), ptr(bias3), ptr(res), ptr(y), ptr(w1), ptr(bias1), ptr(t1), B, H, W, P,
+    t1 = torch.empty(B, H, W, P2, dtype=t2.dtype, device=t2.device)
+    call('dir_conv_c3c1', ptr(t2), ptr(w3), ptr(bias3), ptr(res), ptr(y), ptr(w1), ptr(bias1), ptr(t1), B, H, W, P, P2,
          int(bool(relu3)), int(bool(relu1)), _dtype_code(t2), stream_ptr())
     return y, t1
 

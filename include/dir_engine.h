@@ -163,12 +163,13 @@ int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, cons
                            size_t scratch_bytes, int* ksplit_used, void* stream);
 /* The seam between two bottlenecks as ONE kernel (csrc/conv_c3c1.hip), planes P = 64 or 128:
  *   y  = act3(conv1x1(t2; w3 [4P][P]) + bias3 + res)      the conv3 + bn3 + add + ReLU that closes a block
- *   t1 = act1(conv1x1(y;  w1 [P][4P]) + bias1)            the conv1 + bn1 + ReLU that opens the next one
- * (dirtorch/nets/backbones/resnet.py:78-85 then :70-72).  t2 [B,H,W,P], res / y [B,H,W,4P], t1 [B,H,W,P],
+ *   t1 = act1(conv1x1(y;  w1 [P2][4P]) + bias1)           the conv1 + bn1 + ReLU that opens the next one
+ * (dirtorch/nets/backbones/resnet.py:78-85 then :70-72); P2 = P inside a stage, P2 = 128 after P = 64 for
+ * the layer1 -> layer2 boundary.  t2 [B,H,W,P], res / y [B,H,W,4P], t1 [B,H,W,P2],
  * NHWC 16-bit; conv1 consumes the ROUNDED y, so the pair equals two dir_conv_bn_act calls up to fp32
  * summation order.  The engine uses it for the layer1 / layer2 seams when the map has >= 65536 pixels. */
 int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void* res, void* y, const void* w1,
-                  const float* bias1, void* t1, int B, int H, int W, int P, int relu3, int relu1, int dtype,
+                  const float* bias1, void* t1, int B, int H, int W, int P, int P2, int relu3, int relu1, int dtype,
                   void* stream);
 /* conv3 + bn3 + the block's downsample branch + add + ReLU of a stage's FIRST bottleneck as one GEMM over
  * two K sources (csrc/conv_igemm.hip, DUAL form; dirtorch/nets/backbones/resnet.py:78-85 with :134-141):

@@ -1,0 +1,26 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+TAG=${1:-r2e}
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q -s -p no:cacheprovider -k "two_source or seam or golden or trunk_features" > $O/pytest_new.log 2>&1
+echo "pytest(new) rc=$?" | tee $O/pytest_new.rc
+grep -a " passed\| failed\|^FAILED\|^ERROR\|Error\|bad elements\|out of tolerance" $O/pytest_new.log | tail -20
+run() {
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --layers > $O/bench_$name.json 2> $O/layers_$name.txt
+  echo "$name rc=$? $(python - <<PY
+import json
+try:
+    d=json.loads(open('$O/bench_$name.json').read().strip().splitlines()[-1])
+    print(d['value'], 'img/s', d['ms_per_step'], 'ms/step')
+except Exception as e:
+    print('no result', e)
+PY
+)"
+}
+run all DIRTORCH_AMD_X=1
+run all2 DIRTORCH_AMD_X=1
+run b16 DIRTORCH_AMD_X=1
+grep -a "layer1.2\|layer2.0" $O/layers_all.txt | cut -c1-150

@@ -533,9 +533,9 @@ SEAM_SHAPES = [(2, 37, 29), (4, 80, 80), (1, 5, 7)]
 
 @pytest.mark.parametrize('relu3', [True, False])
 @pytest.mark.parametrize('dname', ['bf16', 'fp16'])
-@pytest.mark.parametrize('P', [64, 128])
+@pytest.mark.parametrize('P,P2', [(64, 64), (128, 128), (64, 128)], ids=['layer1', 'layer2', 'layer1-layer2'])
 @pytest.mark.parametrize('B,H,W', SEAM_SHAPES)
-def test_fused_seam_vs_oracle_and_two_kernel_path(B, H, W, P, dname, relu3):
+def test_fused_seam_vs_oracle_and_two_kernel_path(B, H, W, P, P2, dname, relu3):
     """dir_conv_c3c1 against (a) the fp32 CPU oracle of both convolutions on the same rounded operands
     (the second one fed the ROUNDED output of the first, as the un-fused engine does) and (b) the two
     dir_conv_bn_act launches it replaces, run on the fused kernel's own block output."""
@@ -545,8 +545,8 @@ def test_fused_seam_vs_oracle_and_two_kernel_path(B, H, W, P, dname, relu3):
     w3 = _rand((4 * P, 1, 1, P), 2, (2.0 / P) ** 0.5).to(dt)
     b3 = _rand((4 * P,), 3, 0.2)
     res = F.relu(_rand((B, H, W, 4 * P), 4)).to(dt)
-    w1 = _rand((P, 1, 1, 4 * P), 5, (2.0 / (4 * P)) ** 0.5).to(dt)
-    b1 = _rand((P,), 6, 0.2)
+    w1 = _rand((P2, 1, 1, 4 * P), 5, (2.0 / (4 * P)) ** 0.5).to(dt)
+    b1 = _rand((P2,), 6, 0.2)
     y, t1 = ops.conv_c3c1(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), w1.cuda(), b1.cuda(), relu3=relu3, relu1=True)
     torch.cuda.synchronize()
     ref_y = conv_reference(t2, w3, b3, res, 1, 0, relu3)
