@@ -30,16 +30,20 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>', name)
-    if m:   # <DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK> -> the variant names of csrc/conv_igemm.hip
-        dt, bm, bn, wm, wn, nst, bk, c16, sk = m.groups()
-        return 'conv_igemm<%sx%s_w%sx%s%s%s%s>%s[%s]' % (bm, bn, wm, wn, '_s' + nst if nst != '2' else '',
-                                                        '_k' + bk if bk != '64' else '',
-                                                        '/splitk' if sk == 'true' else '',
-                                                        '/stem' if c16 == 'true' else '', dt.lower())
-    m = re.search(r'conv1x1_persist_kernel<dir::(\w+)>', name)
+    m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\w+))?>', name)
+    if m:   # <DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK[, DUAL]> -> the variant names of csrc/conv_igemm.hip
+        dt, bm, bn, wm, wn, nst, bk, c16, sk, dual = m.groups()
+        return 'conv_igemm<%sx%s_w%sx%s%s%s%s%s>%s[%s]' % (bm, bn, wm, wn, '_s' + nst if nst != '2' else '',
+                                                          '_k' + bk if bk != '64' else '',
+                                                          '/splitk' if sk == 'true' else '',
+                                                          '/dual' if dual == 'true' else '',
+                                                          '/stem' if c16 == 'true' else '', dt.lower())
+    m = re.search(r'conv_c3c1_kernel<dir::(\w+), (\d+), (\w+), (\d+)>', name)
     if m:
-        return 'conv_igemm<256x256_persist1x1>[%s]' % m.group(1).lower()
+        return 'conv_c3c1<%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv1x1_persist_kernel<dir::(\w+)(?:, (\w+), (\w+))?>', name)
+    if m:
+        return 'conv_igemm<256x256_persist1x1%s>[%s]' % ('_x3' if m.group(2) == 'true' else '', m.group(1).lower())
     m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)', name)
     if m:
         return 'conv_igemm<256x%s_patch3x3>[%s]' % (m.group(2), m.group(1).lower())
@@ -108,7 +112,7 @@ def pmc(fd, wd, out, traffic=None):
 
 
 # ---- per-kernel roofline table ---------------------------------------------------------------------
-ENGINE_PREFIX = ('conv_igemm<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
+ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
 PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
 
 
