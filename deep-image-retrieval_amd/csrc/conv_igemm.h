@@ -33,13 +33,6 @@ struct ConvArgs {
     // pixel (b, oh, ow) reads x2 pixel (b, oh*stride2, ow*stride2)
     int H2, W2, stride2;
     uint32_t x2_bytes;
-    // K-blocked layout of a [M][C] activation tensor: [ceil(M/256)][C/64][256 px][64 ch], i.e. the 64-channel
-    // slice of a 256-pixel tile is ONE contiguous 32 KB run.  A 1x1 conv over wide rows (layer3: 1024
-    // channels = 2 KB per pixel) otherwise fetches, per K-step, 128 bytes out of each of 256 rows 2 KB
-    // apart and comes back to every DRAM page 16 times, microseconds apart (3.9 TB/s measured); blocked, a
-    // K-step of the pixel operand is a single 32 KB stream.  Used between conv_wreg (producer: y_blk;
-    // residual consumer: res_blk) and conv_persist (consumer: x_blk) inside layer3.
-    int x_blk, res_blk, y_blk;
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)

@@ -702,10 +702,6 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (!conv_variant_admissible(variant, a))
         return fail(DIR_ERR_INVALID, "conv: variant not admissible for this shape");
     const ConvVariant& cv = kVariants[variant];
-    // K-blocked tensors are understood by the persistent 1x1 kernel (source) and the register-stationary
-    // one (residual, output) only: anything else would silently read the wrong layout
-    if ((a.x_blk && cv.kind != 2 && cv.kind != 4) || ((a.res_blk || a.y_blk) && cv.kind != 3))
-        return fail(DIR_ERR_STATE, std::string("conv: variant ") + cv.name + " cannot address a K-blocked tensor");
     if (a.ksplit > 1) {
         if (cv.launch_sk[0] == nullptr || cin16)
             return fail(DIR_ERR_INVALID, "conv: this variant has no split-K form");

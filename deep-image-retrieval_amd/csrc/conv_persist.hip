@@ -72,9 +72,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         for (int i = 0; i < NA; ++i) {
             const int m = tile_m * BM + i * 64 + (tid >> 3);
             uint32_t off;
-            if (a.x_blk) {   // K-blocked source (flat only): tile-major, then 64-channel slice, then pixel row
-                off = (uint32_t)tile_m * (uint32_t)(a.Cin * 512) + (uint32_t)((i * 64 + (tid >> 3)) * 128 + srcchunk * 16);
-            } else if (a.flat) {
+            if (a.flat) {
                 off = (uint32_t)((m * a.Cin + srcchunk * 8) * 2);
             } else {  // strided 1x1 (downsample): output pixel -> input pixel
                 const uint32_t mm = m < a.M ? (uint32_t)m : 0u;
@@ -91,10 +89,9 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         for (int i = 0; i < NB; ++i)
             wvoff[i] = (uint32_t)(((tile_n * BN + i * 64 + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
     };
-    const int xkstep = a.x_blk ? 256 * 128 : 128;   // bytes between K-steps of the pixel operand
     auto issue_x = [&](int t, char* dst) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) dma16q(rsrc_x, dst + (i * NT + wave * 64) * 16, xvoff[i], t * xkstep);
+        for (int i = 0; i < NA; ++i) dma16q(rsrc_x, dst + (i * NT + wave * 64) * 16, xvoff[i], t * 128);
     };
     auto issue_w = [&](int t, char* dst) {
 #pragma unroll
@@ -327,10 +324,6 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
-    if (a.x_blk) {   // K-blocked source: whole 256-pixel tiles
-        if (!b.flat || a.res_blk || a.y_blk) return hipErrorInvalidValue;
-        b.x_bytes = (uint32_t)((size_t)ceil_div(a.M, 256) * 256 * a.Cin * 2);
-    }
     // exact n / d for n < 2^31 (same constants as conv_igemm.hip)
     auto fd = [](uint32_t d, uint32_t& mul, uint32_t& shr) {
         if (d <= 1) { mul = 0; shr = 0; return; }

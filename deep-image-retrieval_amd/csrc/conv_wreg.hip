@@ -49,13 +49,9 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     // residual loads and output stores go through bounds-checked descriptors too: a ragged last tile
     // needs no branch (out-of-range rows read zeros / drop the store), and with every VMEM op of the
     // loop unconditional the compiler's vmcnt bookkeeping is exact instead of "wait for everything"
-    // (K-blocked tensors - ConvArgs::res_blk / y_blk - are padded to whole 256-pixel tiles)
     const uint32_t y_bytes = (uint32_t)((size_t)a.M * a.Cout * 2);
-    const uint32_t yb_bytes = (uint32_t)((size_t)((a.M + 255) / 256) * 256 * a.Cout * 2);
-    const __amdgpu_buffer_rsrc_t rsrc_r =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res_blk ? yb_bytes : y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_y =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_blk ? yb_bytes : y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, y_bytes, 0x00020000);
 
     // work split: workgroup g serves channel slice g % nsl, pixel tiles (g / nsl) + i * (G / nsl)
     const int nsl = a.Cout / 512;
@@ -118,18 +114,10 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     // residual of one 32-pixel strip (this wave's 64 channels): 4 x 16 B per lane
     const uint32_t ncol2 = (uint32_t)((n_wave + ecol) * 2);
     auto row_off = [&](int m) { return m < a.M ? (uint32_t)m * (uint32_t)(a.Cout * 2) + ncol2 : kOOBr; };
-    // the same element in the K-blocked layout [M/256][Cout/64][256][64]: this wave's 64 channels are one
-    // 64-channel slice (n_wave is a multiple of 64), 8 consecutive lanes cover one 128-byte pixel row of it
-    const uint32_t blk_col = (uint32_t)(n_wave >> 6) * (256u * 128u) + (uint32_t)(ecol * 2);
-    auto blk_off = [&](int m) {
-        return m < a.M ? (uint32_t)(m >> 8) * (uint32_t)(a.Cout * 512) + blk_col + (uint32_t)((m & 255) * 128) : kOOBr;
-    };
-    auto res_off = [&](int m) { return a.res_blk ? blk_off(m) : row_off(m); };
-    auto out_off = [&](int m) { return a.y_blk ? blk_off(m) : row_off(m); };
     auto load_res = [&](int t, int j, u32x4_t* r) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass)
-            r[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, res_off(t * BM + j * 32 + pass * 8 + erow), 0, 0);
+            r[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, row_off(t * BM + j * 32 + pass * 8 + erow), 0, 0);
     };
 
     u32x4_t xr[NX];
@@ -216,7 +204,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
                     u32x4_t ov;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, out_off(m), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row_off(m), 0, 0);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

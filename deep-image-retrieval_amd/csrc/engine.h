@@ -79,13 +79,8 @@ struct dir_engine {
     int plan(int B, int H, int W, dir::Plan* p) const;
     int forward(const void* img, int B, int H, int W, int fmt, float* desc_out, void* feat_out,
                 int* fh, int* fw, int* fc, void* ws, size_t ws_bytes, hipStream_t stream);
-    // blk: K-blocked layout flags of the tensors (1 = x, 2 = res, 4 = y; ConvArgs::x_blk ...)
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
-                 int H, int W, int OH, int OW, hipStream_t stream, int blk = 0);
-    void conv_args(const dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B, int H, int W,
-                   int OH, int OW, dir::ConvArgs* a) const;
-    // kind (ConvVariant::kind) of the kernel run_conv would use for this layer and shape
-    int planned_kind(const dir::ConvLayer& L, int B, int H, int W, int OH, int OW, bool has_res) const;
+                 int H, int W, int OH, int OW, hipStream_t stream);
     // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes
     // do not qualify and nothing was launched
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,

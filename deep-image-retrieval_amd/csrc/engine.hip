@@ -293,8 +293,7 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
             t1 = std::max(t1, (size_t)B * oh * ow * c1.Cout * 2);
         }
         if (bd.down >= 0) ds = std::max(ds, (size_t)B * oh * ow * convs[bd.down].Cout * 2);
-        // (+ up to 255 pixel rows: the K-blocked layout of layer3's block outputs holds whole 256-pixel tiles)
-        io = std::max(io, ((size_t)B * oh * ow + 255) / 256 * 256 * cl.Cout * 2);
+        io = std::max(io, (size_t)B * oh * ow * cl.Cout * 2);
         h = oh;
         w = ow;
         if ((int)bi == x4_block) {  // FPN heads keep x4; the lateral path reuses t1 / t2 / a ping-pong buffer
@@ -350,9 +349,9 @@ int dir_engine::prof_end(hipStream_t stream) {
 }
 
 // ---- one convolution ----------------------------------------------------------------------------
-void dir_engine::conv_args(const ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B, int H,
-                           int W, int OH, int OW, ConvArgs* pa) const {
-    ConvArgs& a = *pa;
+int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
+                         int H, int W, int OH, int OW, hipStream_t stream) {
+    ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
     a.w = L.d_w;
@@ -382,26 +381,6 @@ void dir_engine::conv_args(const ConvLayer& L, const uint16_t* x, const uint16_t
     a.M = B * OH * OW;
     a.Ktot = a.R * a.S * a.Cin;
     a.T = a.Ktot / 64;
-}
-
-int dir_engine::planned_kind(const ConvLayer& L, int B, int H, int W, int OH, int OW, bool has_res) const {
-    static const uint16_t dummy = 0;   // host-side decision only: pointers are compared with null, never read
-    ConvArgs a;
-    conv_args(L, &dummy, has_res ? &dummy : nullptr, const_cast<uint16_t*>(&dummy), B, H, W, OH, OW, &a);
-    int variant = -1;
-    auto it = L.tuned.find(a.M);
-    if (it != L.tuned.end() && conv_variant_admissible(it->second, a)) variant = it->second;
-    if (variant < 0) variant = conv_pick_variant(a);
-    return variant < 0 ? -1 : conv_variant(variant).kind;
-}
-
-int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
-                         int H, int W, int OH, int OW, hipStream_t stream, int blk) {
-    ConvArgs a;
-    conv_args(L, x, res, y, B, H, W, OH, OW, &a);
-    a.x_blk = blk & 1;
-    a.res_blk = (blk >> 1) & 1;
-    a.y_blk = (blk >> 2) & 1;
     const double macs = (double)a.M * L.Cout * (double)(L.R * L.S * L.Cin);  // true taps (stem: 147)
     const double bytes = 2.0 * ((double)B * H * W * a.Cin + (double)a.M * L.Cout * (res ? 2 : 1) +
                                 (double)L.Cout * a.Ktot);
@@ -630,8 +609,6 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     uint16_t* x4 = nullptr;
     int h = p.PH, w = p.PW, h4 = 0, w4 = 0;
     bool t1_ready = false;
-    bool cur_blk = false, nxt_blk = false;   // K-blocked layout of `cur` / of the block output being produced
-    const bool blk_layout = getenv("DIRTORCH_AMD_NO_BLK") == nullptr;   // (env: A/B and bisecting)
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
@@ -666,25 +643,12 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         }
         if (desc.bottleneck) {
             if (!t1_ready) {   // (the previous block's fused seam kernel may have produced t1 already)
-                rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream, cur_blk ? 1 : 0);
+                rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream);
                 if (rc != DIR_OK) return rc;
             }
             t1_ready = false;
             rc = run_conv(convs[bd.conv2], t1, nullptr, t2, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
-            // K-blocked block output (ConvArgs::x_blk): this block's conv3 must be the register-stationary
-            // kernel (the producer that can write it) and the NEXT block must read it through the persistent
-            // 1x1 kernel (conv1) and the register-stationary one (conv3's residual) - the interior of layer3
-            nxt_blk = false;
-            if (blk_layout && !keep && !ds_dual && !ds_in_seam && !tuning && bi + 1 < blocks.size()) {
-                const BlockDef& nb = blocks[bi + 1];
-                if (nb.down < 0 && nb.stride == 1 && convs[nb.conv1].Cin >= 1024 && ((long)B * oh * ow) % 256 == 0) {
-                    const int k3 = planned_kind(convs[bd.conv3], B, oh, ow, oh, ow, true);
-                    const int k1n = planned_kind(convs[nb.conv1], B, oh, ow, oh, ow, false);
-                    const int k3n = planned_kind(convs[nb.conv3], B, oh, ow, oh, ow, true);
-                    nxt_blk = k3 == 3 && (k1n == 2 || k1n == 4) && k3n == 3;
-                }
-            }
             int fused = 0;
             if (ds_dual) {
                 rc = run_conv_dual(convs[bd.conv3], convs[bd.down], t2, cur, nxt, B, h, w, oh, ow, stream, &fused, false);
@@ -701,8 +665,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             if (fused == 1) {
                 t1_ready = true;
             } else if (!fused) {
-                rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream,
-                              (cur_blk ? 2 : 0) | (nxt_blk ? 4 : 0));
+                rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
                 if (rc != DIR_OK) return rc;
             }
         } else {
@@ -712,7 +675,6 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             if (rc != DIR_OK) return rc;
         }
         cur = nxt;
-        cur_blk = nxt_blk;
         h = oh;
         w = ow;
         if (keep) {

@@ -275,32 +275,3 @@ def test_fused_seams_inside_the_network(monkeypatch):
     monkeypatch.setenv('DIRTORCH_AMD_C3C1', '0')
     d_plain = make_net('resnet50', {}, sd, 'bf16')(x[:2, :256, :256].contiguous())
     assert np.all(1 - O.cosine(d_forced.cpu().numpy(), d_plain.cpu().numpy()) < 1e-5)
-
-
-def test_k_blocked_layout_inside_layer3_is_bit_identical(monkeypatch):
-    """Inside layer3 (batch >= ~12 at 1024^2) block outputs travel between conv_wreg (producer, residual
-    consumer) and conv_persist (conv1) in the K-blocked layout [M/256][C/64][256][64] (ConvArgs::x_blk): a
-    different ADDRESS of every element, the same arithmetic - so features and descriptors must be bit for
-    bit those of the NHWC run.  ResNet-50 at 16 x 1024^2: blocks layer3.1 .. layer3.4 write blocked."""
-    import dir_oracle as O
-    sd = O.synth_state_dict('resnet50', seed=7)
-    g = torch.Generator(device='cuda').manual_seed(4)
-    x = torch.randint(0, 256, (16, 1024, 1024, 3), generator=g, dtype=torch.uint8, device='cuda')
-
-    def run(blocked):
-        if blocked:
-            monkeypatch.delenv('DIRTORCH_AMD_NO_BLK', raising=False)
-        else:
-            monkeypatch.setenv('DIRTORCH_AMD_NO_BLK', '1')
-        net = make_net('resnet50', {}, sd, 'bf16')
-        f = net.forward_features(x)
-        net.set_profiling(True)
-        d = net(x)
-        return f, d, {r['name']: r['kernel'] for r in net.get_profile()}
-
-    f0, d0, n0 = run(False)
-    f1, d1, n1 = run(True)
-    assert n1['layer3.2.conv1'].startswith('conv_igemm<256x256_persist1x1') and n1['layer3.2.conv3'] == 'conv_igemm<64x512_wreg1x1>', n1
-    assert n0 == n1                      # same kernels either way
-    assert torch.equal(f0, f1) and torch.equal(d0, d1)
-    assert torch.isfinite(d1).all()
