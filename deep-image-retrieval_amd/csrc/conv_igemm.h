@@ -51,7 +51,8 @@ struct ConvVariant {
     int kind;                  // 0 = implicit GEMM (conv_igemm.hip), 1 = LDS-patch 3x3 (conv_patch.hip),
                                // 2 = persistent 256x256 1x1 (conv_persist.hip),
                                // 3 = register-stationary weights 1x1 (conv_wreg.hip),
-                               // 4 = kind 2 with the pixel operand three K-steps deep (conv_persist.hip, XDEEP)
+                               // 4 = kind 2 with the pixel operand three K-steps deep (conv_persist.hip, XDEEP),
+                               // 5 = LDS-patch 3x3 for wide layers, one 64-channel plane at a time (conv_patch.hip)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
     ConvLaunchFn launch_dual[2]; // two-source K instantiation (ConvArgs::x2: conv3 + downsample in one GEMM), or nullptr
 };
@@ -62,6 +63,8 @@ bool conv1x1_wreg_admissible(const ConvArgs& a);
 hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_c3c1_admissible(const ConvArgs& a);
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+bool conv_patch3x3s_admissible(const ConvArgs& a);
+hipError_t conv_patch3x3s_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

@@ -500,6 +500,8 @@ static const ConvVariant kVariants[] = {
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
+    // ... for the wide 3x3 layers (256 / 512 channels): the patch one 64-channel plane at a time, Cout tiled by 256
+    {"256x256_patch3x3s", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 5, {nullptr, nullptr}, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}, {nullptr, nullptr}},
     // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
@@ -516,6 +518,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (v < 0 || v >= kNumVariants) return false;
     const ConvVariant& cv = kVariants[v];
     if (cv.kind == 1) return a.Cout == cv.BN && conv_patch3x3_admissible(a);
+    if (cv.kind == 5) return conv_patch3x3s_admissible(a);
     if (cv.kind == 2) return conv1x1_persist_admissible(a);
     if (cv.kind == 4) return conv1x1_persist_admissible(a) && a.res == nullptr;   // the deep-X form has no residual path
     if (cv.kind == 3) return conv1x1_wreg_admissible(a);
@@ -556,7 +559,7 @@ int conv_pick_variant(const ConvArgs& a) {
     }
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };
-    Cand c[8];
+    Cand c[10];
     int n = 0;
     if (T <= 1 || a.Cout % 128 != 0) {
         c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
@@ -567,6 +570,10 @@ int conv_pick_variant(const ConvArgs& a) {
         // those are not short of HBM requests in flight, so they keep the 2-slot form.
         static const bool no_x3 = getenv("DIRTORCH_AMD_NO_X3") != nullptr;      // A/B and bisecting
         const bool x3 = a.R * a.S == 1 && !a.res && !no_x3 && T >= 32;
+        // 3x3 over 256 / 512 channels: the plane-at-a-time patch kernel (conv_patch.hip) - falls through to the
+        // 16-wave implicit-GEMM tile where it is not admissible (stride 2, odd widths) or too few tiles
+        static const bool no_ps = getenv("DIRTORCH_AMD_NO_PATCHS") != nullptr;  // A/B and bisecting
+        if (a.R * a.S > 1 && !no_ps) c[n++] = {"256x256_patch3x3s", 1};
         c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
@@ -710,6 +717,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
         if (a.ksplit > a.Ktot / cv.BK) return fail(DIR_ERR_INVALID, "conv: more K slices than K-steps");
     }
     hipError_t e = cv.kind == 1   ? conv_patch3x3_launch(a, dtype, stream)
+                   : cv.kind == 5 ? conv_patch3x3s_launch(a, dtype, stream)
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
                    : cv.kind == 4 ? conv1x1_persist_launch(a, dtype, stream, true)
                    : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)

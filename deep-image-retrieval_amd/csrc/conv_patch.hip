@@ -258,4 +258,226 @@ hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream
     return dtype == DIR_BF16 ? launch_patch<BF16, 128, 512>(a, stream) : launch_patch<FP16, 128, 512>(a, stream);
 }
 
+
+// ---- wide layers: the patch one 64-channel plane at a time ---------------------------------------------
+// layer3 / layer4 (256 -> 256, 512 -> 512 at 64^2 / 32^2 for a 1024^2 image): the whole-depth patch does not
+// fit (4 or 8 planes of 48 KB), so the K loop goes plane-major - for each 64-channel plane: its 10 x 34
+// patch (double-buffered, the next plane arrives one DMA instruction per tap underneath this plane's nine
+// taps), then nine weight stages [256][64] through a 2-slot ring.  Per 256 x 256 x 64 K-step the CU pulls
+// 32 KB of weights + 5.3 KB of patch instead of the implicit-GEMM form's 32 + 32 KB: that form spends
+// 1.8 us per K-step waiting on a 64 KB stage against 0.86 us of MFMA work (profiles/r02: MfmaUtil 0.53).
+// Cout is tiled by 256 (blockIdx fastest, neighbours share the patch through L2).  LDS: 2 x 48 KB of
+// planes + 2 x 32 KB of weights = all 160 KiB; the epilogue staging aliases them after the K loop.
+template <class DT, int CIN>
+__global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
+    constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int KC = CIN / 64, NTH = 512, BN = 256;
+    constexpr int NPL = (PP * 8 + NTH - 1) / NTH;       // 6 DMA instructions per lane per plane
+    constexpr int PLANE_BYTES = NPL * NTH * 16;         // 49152
+    constexpr int TN = 4, TMR = 2;                      // wave tile: 128 channels x 2 output rows
+    constexpr int WSTAGE = BN * 128, NBW = BN * 8 / NTH;   // 32 KB, 4 instructions per lane
+    constexpr int WOFF = 2 * PLANE_BYTES;
+    constexpr int T = 9 * KC;
+    constexpr int EROW = TN * 128 + 16;
+    typedef typename DT::frag_t frag_t;
+    static_assert(CIN % 64 == 0 && WOFF + 2 * WSTAGE <= 160 * 1024, "shape / LDS map");
+    static_assert(NPL <= 9, "the next plane must fit under the nine taps of this one");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int wrow = wave & 3, wn = wave >> 2;
+
+    const int tiles_n = a.Cout / BN;
+    const int tiles_x = (a.OW + TW - 1) / TW;
+    const int tiles_y = (a.OH + TH - 1) / TH;
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wg % tiles_n;
+    wg /= tiles_n;
+    const int tx = wg % tiles_x;
+    wg /= tiles_x;
+    const int ty = wg % tiles_y;
+    const int b = wg / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+    // patch: per-lane source offsets of plane 0 (plane kc adds kc * 128 bytes through the scalar offset)
+    uint32_t pvoff[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int P = i * NTH + tid;
+        const int p = P >> 3, slot = P & 7;
+        const int py = p / PW, px = p - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = p < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        pvoff[i] = ok ? (uint32_t)((((b * a.H + iy) * a.W + ix) * CIN + ((slot ^ ((p >> 1) & 7)) << 3)) * 2) : kOOBp;
+    }
+    auto issue_plane_piece = [&](int kc, int i) {   // one of the NPL instructions of plane kc
+        dma16p(rsrc_x, smem + (kc & 1) * PLANE_BYTES + (i * NTH + wave * 64) * 16, pvoff[i], kc * 128);
+    };
+    const int srcchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    uint32_t wvoff[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+        wvoff[i] = (uint32_t)(((tile_n * BN + i * (NTH / 8) + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
+    // K-step t = (plane kc = t / 9, tap = t % 9); its weights are K-slice (tap * KC + kc) of [Cout][3][3][Cin]
+    auto issue_w = [&](int kc, int tap, int slot) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+            dma16p(rsrc_w, smem + WOFF + slot * WSTAGE + (i * NTH + wave * 64) * 16, wvoff[i], (tap * KC + kc) * 128);
+    };
+
+    f32x16_t acc[TN][TMR];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + tile_n * BN + (wn * TN + i) * 32 + 8 * g + 4 * lhi);
+#pragma unroll
+            for (int j = 0; j < TMR; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b4[e];
+        }
+
+    const int wswz = (lane >> 1) & 7;
+    int woffk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) woffk[ks] = lrow * 128 + (((2 * ks + lhi) ^ wswz) << 4);
+
+    // prologue: plane 0 whole, then the first weight stage
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) issue_plane_piece(0, i);
+    issue_w(0, 0, 0);
+
+    int kc = 0, tap = 0, r = 0, s = 0;     // the step being COMPUTED
+    for (int t = 0; t < T; ++t) {
+        // everything issued so far is at most one step old: stage t (and the pieces of the next plane
+        // issued alongside earlier stages) must have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // ... for every wave; weight slot (t+1)&1 and - at tap 0 - plane slot (kc+1)&1 are free
+        if (t + 1 < T) {
+            const int ntap = tap == 8 ? 0 : tap + 1, nkc = tap == 8 ? kc + 1 : kc;
+            issue_w(nkc, ntap, (t + 1) & 1);
+        }
+        if (kc + 1 < KC && tap < NPL) {    // the next plane trickles in underneath this plane's taps
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (i == tap) issue_plane_piece(kc + 1, i);
+        }
+        const char* wst = smem + WOFF + (t & 1) * WSTAGE;
+        const char* plane = smem + (kc & 1) * PLANE_BYTES;
+        frag_t xf[TMR][4];
+#pragma unroll
+        for (int j = 0; j < TMR; ++j) {
+            const int p = (wrow * TMR + j + r) * PW + s + lrow;
+            const int swz = (p >> 1) & 7;
+            const char* row = plane + p * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xf[j][ks] = *(const frag_t*)(row + (((2 * ks + lhi) ^ swz) << 4));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            frag_t wf[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *(const frag_t*)(wst + (wn * TN + i) * 4096 + woffk[ks]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TMR; ++j) acc[i][j] = DT::mfma32(wf[i], xf[j][ks], acc[i][j]);
+        }
+        if (++tap == 9) {
+            tap = 0;
+            r = s = 0;
+            ++kc;
+        } else if (++s == 3) {
+            s = 0;
+            ++r;
+        }
+    }
+    __syncthreads();  // planes and weight slots become epilogue staging
+
+    char* ebase = smem + wave * (32 * EROW);
+    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
+    const int ecol = (lane % LPR) * 8;
+    const int erow = lane / LPR;
+    const int ncol = tile_n * BN + wn * TN * 32 + ecol;
+#pragma unroll
+    for (int j = 0; j < TMR; ++j) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4_t v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *(f32x4_t*)(ebase + lrow * EROW + (i * 32 + 8 * g + 4 * lhi) * 4) = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int oy = oy0 + wrow * TMR + j;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int mrow = pass * RPP + erow;
+            const f32x4_t f0 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4);
+            const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
+            const int ox = ox0 + mrow;
+            if (oy < a.OH && ox < a.OW) {
+                float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+                const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + ncol;
+                if (a.res) {
+                    const u32x4_t rv = gload16(a.res + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo, hi;
+                        DT::unpack(rv[e], lo, hi);
+                        v[2 * e] += lo;
+                        v[2 * e + 1] += hi;
+                    }
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                u32x4_t ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
+                gstore16(a.y + o, ov);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+bool conv_patch3x3s_admissible(const ConvArgs& a) {
+    return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.H == a.OH && a.W == a.OW &&
+           (a.Cin == 256 || a.Cin == 512) && a.Cout % 256 == 0;
+}
+
+template <class DT, int C>
+static hipError_t launch_patch_s(const ConvArgs& a, hipStream_t stream) {
+    constexpr int LDS = 2 * 6 * 512 * 16 + 2 * 256 * 128;   // two planes + two weight stages = 160 KiB
+    static_assert(LDS <= 160 * 1024 && LDS >= 8 * 32 * (4 * 128 + 16), "LDS map (the staging area aliases it)");
+    auto kern = conv_patch3x3s_kernel<DT, C>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
+    ConvArgs b = a;
+    b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
+    b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
+    const long blocks = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) * (a.Cout / 256);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), LDS, stream, b);
+    return hipGetLastError();
+}
+
+hipError_t conv_patch3x3s_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
+    if (a.Cin == 256)
+        return dtype == DIR_BF16 ? launch_patch_s<BF16, 256>(a, stream) : launch_patch_s<FP16, 256>(a, stream);
+    return dtype == DIR_BF16 ? launch_patch_s<BF16, 512>(a, stream) : launch_patch_s<FP16, 512>(a, stream);
+}
+
 }  // namespace dir
