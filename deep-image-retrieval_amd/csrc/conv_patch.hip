@@ -262,12 +262,14 @@ hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream
 // ---- wide layers: the patch one 64-channel plane at a time ---------------------------------------------
 // layer3 / layer4 (256 -> 256, 512 -> 512 at 64^2 / 32^2 for a 1024^2 image): the whole-depth patch does not
 // fit (4 or 8 planes of 48 KB), so the K loop goes plane-major - for each 64-channel plane: its 10 x 34
-// patch (double-buffered, the next plane arrives one DMA instruction per tap underneath this plane's nine
-// taps), then nine weight stages [256][64] through a 2-slot ring.  Per 256 x 256 x 64 K-step the CU pulls
-// 32 KB of weights + 5.3 KB of patch instead of the implicit-GEMM form's 32 + 32 KB: that form spends
-// 1.8 us per K-step waiting on a 64 KB stage against 0.86 us of MFMA work (profiles/r02: MfmaUtil 0.53).
-// Cout is tiled by 256 (blockIdx fastest, neighbours share the patch through L2).  LDS: 2 x 48 KB of
-// planes + 2 x 32 KB of weights = all 160 KiB; the epilogue staging aliases them after the K loop.
+// patch, then nine weight stages [256][64] through a 3-slot ring.  What bounds the implicit-GEMM form on
+// these layers is neither MFMA nor bandwidth but the LATENCY of a stage under load: ~1.8 us from issue to
+// landed against 0.86 us of MFMA work per 256 x 256 x 64 K-step, with room for only ONE 64 KB stage in
+// flight (profiles/r02: waves parked 48 % of their cycles, MfmaUtil 0.53).  Streaming only the weights
+// (32 KB per K-step; the patch is 5.3 KB per K-step amortised) leaves LDS for TWO stages in flight:
+// 48 KB plane + 3 x 32 KB = 144 KB.  The plane is single-buffered - the next one is requested when the
+// last tap of this one is done, with the first two weight stages of the next plane already in flight.
+// Cout is tiled by 256 (blockIdx fastest, neighbours share the patch through L2).
 template <class DT, int CIN>
 __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
     constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
@@ -276,12 +278,12 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
     constexpr int PLANE_BYTES = NPL * NTH * 16;         // 49152
     constexpr int TN = 4, TMR = 2;                      // wave tile: 128 channels x 2 output rows
     constexpr int WSTAGE = BN * 128, NBW = BN * 8 / NTH;   // 32 KB, 4 instructions per lane
-    constexpr int WOFF = 2 * PLANE_BYTES;
+    constexpr int NSTW = 3;
+    constexpr int WOFF = PLANE_BYTES;
     constexpr int T = 9 * KC;
     constexpr int EROW = TN * 128 + 16;
     typedef typename DT::frag_t frag_t;
-    static_assert(CIN % 64 == 0 && WOFF + 2 * WSTAGE <= 160 * 1024, "shape / LDS map");
-    static_assert(NPL <= 9, "the next plane must fit under the nine taps of this one");
+    static_assert(CIN % 64 == 0 && WOFF + NSTW * WSTAGE <= 160 * 1024, "shape / LDS map");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -317,8 +319,9 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
         const bool ok = p < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         pvoff[i] = ok ? (uint32_t)((((b * a.H + iy) * a.W + ix) * CIN + ((slot ^ ((p >> 1) & 7)) << 3)) * 2) : kOOBp;
     }
-    auto issue_plane_piece = [&](int kc, int i) {   // one of the NPL instructions of plane kc
-        dma16p(rsrc_x, smem + (kc & 1) * PLANE_BYTES + (i * NTH + wave * 64) * 16, pvoff[i], kc * 128);
+    auto issue_plane = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) dma16p(rsrc_x, smem + (i * NTH + wave * 64) * 16, pvoff[i], kc * 128);
     };
     const int srcchunk = (tid & 7) ^ ((tid >> 4) & 7);
     uint32_t wvoff[NBW];
@@ -326,10 +329,11 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
     for (int i = 0; i < NBW; ++i)
         wvoff[i] = (uint32_t)(((tile_n * BN + i * (NTH / 8) + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
     // K-step t = (plane kc = t / 9, tap = t % 9); its weights are K-slice (tap * KC + kc) of [Cout][3][3][Cin]
-    auto issue_w = [&](int kc, int tap, int slot) {
+    auto issue_w = [&](int t, int slot) {
+        const int kcw = t / 9, tapw = t - kcw * 9;
 #pragma unroll
         for (int i = 0; i < NBW; ++i)
-            dma16p(rsrc_w, smem + WOFF + slot * WSTAGE + (i * NTH + wave * 64) * 16, wvoff[i], (tap * KC + kc) * 128);
+            dma16p(rsrc_w, smem + WOFF + slot * WSTAGE + (i * NTH + wave * 64) * 16, wvoff[i], (tapw * KC + kcw) * 128);
     };
 
     f32x16_t acc[TN][TMR];
@@ -349,34 +353,34 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) woffk[ks] = lrow * 128 + (((2 * ks + lhi) ^ wswz) << 4);
 
-    // prologue: plane 0 whole, then the first weight stage
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) issue_plane_piece(0, i);
-    issue_w(0, 0, 0);
-
+    // prologue: plane 0, then weight stages 0 and 1 (issue order matters for the counted waits below)
+    issue_plane(0);
+    issue_w(0, 0);
+    issue_w(1, 1);
+    int issued = 2;                        // weight stages issued so far
+    int slot_c = 0, slot_i = 2;
     int kc = 0, tap = 0, r = 0, s = 0;     // the step being COMPUTED
     for (int t = 0; t < T; ++t) {
-        // everything issued so far is at most one step old: stage t (and the pieces of the next plane
-        // issued alongside earlier stages) must have landed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // ... for every wave; weight slot (t+1)&1 and - at tap 0 - plane slot (kc+1)&1 are free
-        if (t + 1 < T) {
-            const int ntap = tap == 8 ? 0 : tap + 1, nkc = tap == 8 ? kc + 1 : kc;
-            issue_w(nkc, ntap, (t + 1) & 1);
+        // need weight stage t (and, at tap 0, this plane - issued BEFORE stage t at a plane switch, see
+        // below); may leave the newest stage, t + 1, in flight
+        if (issued > t + 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NBW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (kc + 1 < KC && tap < NPL) {    // the next plane trickles in underneath this plane's taps
-#pragma unroll
-            for (int i = 0; i < NPL; ++i)
-                if (i == tap) issue_plane_piece(kc + 1, i);
+        __builtin_amdgcn_s_barrier();      // stage t landed for every wave; slot of stage t - 1 is free
+        if (issued < T) {
+            issue_w(issued, slot_i);
+            ++issued;
+            if (++slot_i == NSTW) slot_i = 0;
         }
-        const char* wst = smem + WOFF + (t & 1) * WSTAGE;
-        const char* plane = smem + (kc & 1) * PLANE_BYTES;
+        const char* wst = smem + WOFF + slot_c * WSTAGE;
         frag_t xf[TMR][4];
 #pragma unroll
         for (int j = 0; j < TMR; ++j) {
             const int p = (wrow * TMR + j + r) * PW + s + lrow;
             const int swz = (p >> 1) & 7;
-            const char* row = plane + p * 128;
+            const char* row = smem + p * 128;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) xf[j][ks] = *(const frag_t*)(row + (((2 * ks + lhi) ^ swz) << 4));
         }
@@ -390,16 +394,27 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TMR; ++j) acc[i][j] = DT::mfma32(wf[i], xf[j][ks], acc[i][j]);
         }
+        if (++slot_c == NSTW) slot_c = 0;
         if (++tap == 9) {
             tap = 0;
             r = s = 0;
             ++kc;
+            if (kc < KC) {
+                // plane switch: every wave must be done reading the old plane before the new one may land.
+                // The two weight stages already in flight (t + 1, t + 2) are OLDER than the plane request, so
+                // the next step's counted wait - which may leave only the newest weight stage outstanding -
+                // cannot be used as is: wait for everything once per plane instead.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_plane(kc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else if (++s == 3) {
             s = 0;
             ++r;
         }
     }
-    __syncthreads();  // planes and weight slots become epilogue staging
+    __syncthreads();  // plane and weight slots become epilogue staging
 
     char* ebase = smem + wave * (32 * EROW);
     constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
@@ -461,7 +476,7 @@ bool conv_patch3x3s_admissible(const ConvArgs& a) {
 
 template <class DT, int C>
 static hipError_t launch_patch_s(const ConvArgs& a, hipStream_t stream) {
-    constexpr int LDS = 2 * 6 * 512 * 16 + 2 * 256 * 128;   // two planes + two weight stages = 160 KiB
+    constexpr int LDS = 6 * 512 * 16 + 3 * 256 * 128;   // one plane + three weight stages = 144 KiB
     static_assert(LDS <= 160 * 1024 && LDS >= 8 * 32 * (4 * 128 + 16), "LDS map (the staging area aliases it)");
     auto kern = conv_patch3x3s_kernel<DT, C>;
     static std::atomic<uint64_t> attr_done{0};
