@@ -10,7 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'oracle')):
+for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 
@@ -23,10 +23,10 @@ def main():
     ap.add_argument('--arch', default='resnet101')
     ap.add_argument('--fmt', default='u8', choices=['u8', 'f32'])
     args = ap.parse_args()
-    import dir_oracle as O
+    import synth
     from dirtorch_amd import nets
     net = nets.create_model(args.arch + '_rmac', pretrained='')
-    net.load_state_dict(O.synth_state_dict(args.arch, seed=7))
+    net.load_state_dict(synth.synth_state_dict(args.arch, seed=7))
     net.cuda().eval()
     B, S = args.batch, args.size
     if args.fmt == 'u8':
@@ -34,7 +34,6 @@ def main():
     else:   # the reference's feed: normalised fp32 NCHW (common.py:214)
         host = [torch.randn(B, 3, S, S).pin_memory() for _ in range(2)]
     dev = [torch.empty_like(h, device='cuda') for h in host]
-    net.autotune = True
     net(dev[0].copy_(host[0]))
     net.autotune = False
     copy_stream = torch.cuda.Stream()

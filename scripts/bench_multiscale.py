@@ -10,7 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'oracle')):
+for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 
@@ -21,13 +21,12 @@ def main():
     ap.add_argument('--size', type=int, default=1200)
     ap.add_argument('--steps', type=int, default=10)
     args = ap.parse_args()
-    import dir_oracle as O
+    import synth
     from dirtorch_amd import nets, ops
     from dirtorch_amd.utils import common, transforms
     net = nets.create_model('resnet101_rmac', pretrained='')
-    net.load_state_dict(O.synth_state_dict('resnet101', seed=7))
+    net.load_state_dict(synth.synth_state_dict('resnet101', seed=7))
     net.cuda().eval()
-    net.autotune = True
     B, S = args.batch, args.size
     img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda')
     scales = [transforms.Scale(0.7071), None, transforms.Scale(1.4142)]
@@ -40,8 +39,7 @@ def main():
             per_scale.append(net(x))
         return common.l2_normalize(common.pool(per_scale, 'gem', 3))
 
-    step()                      # autotune every scale's shapes
-    net.autotune = False
+    step()                      # first touch of every scale's shapes (tiles from the built-in heuristic)
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

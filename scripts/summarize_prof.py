@@ -44,6 +44,9 @@ def short(name):
     m = re.search(r'conv1x1_persist_kernel<dir::(\w+)(?:, (\w+), (\w+))?>', name)
     if m:
         return 'conv_igemm<256x256_persist1x1%s>[%s]' % ('_x3' if m.group(2) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv_patch3x3s_kernel<dir::(\w+), (\d+)>', name)
+    if m:
+        return 'conv_igemm<256x256_patch3x3s>[%s]' % m.group(1).lower()
     m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)', name)
     if m:
         return 'conv_igemm<256x%s_patch3x3>[%s]' % (m.group(2), m.group(1).lower())
