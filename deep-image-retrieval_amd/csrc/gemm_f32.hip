@@ -17,8 +17,6 @@
 #include "dir_common.h"
 #include "pointwise.h"
 
-#include <stdlib.h>
-
 namespace dir {
 
 template <int TJ>
@@ -172,150 +170,6 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
     }
 }
 
-// ---- long P, few Q (the 70 x 10^6 similarity of BASELINE config D) -----------------------------------------
-// The tile loop above fetches, per K-slab, 128 bytes out of each of 128 P rows; with a power-of-two row pitch
-// (D = 2048 floats = 8 KiB) those 128 requests differ only in address bits >= 13 and crowd onto a few HBM
-// channels (1.3 TB/s even with every workgroup's K phase rotated).  Here a slab is 128 floats: each P row
-// contributes 512 contiguous bytes per slab (a wave-wide load covers two rows x 512 B), so a workgroup's
-// requests spread over the channels, and a slab carries 4x the MFMA work (192 MFMAs per wave: 5 us) - longer
-// than the loaded HBM latency, so ONE LDS buffer is enough: slab t+1 waits in registers (28 x 16 B per lane)
-// while slab t is consumed, then replaces it between two barriers.  LDS rows are 512 B; the 16-byte chunk
-// index is XOR-swizzled with (row & 15) so both the fragment reads (16-lane groups of distinct rows) and
-// the staging writes stay bank-conflict free.  Same arithmetic as gemm_nt_f32_kernel (exact fp32 MFMA,
-// k-ordered fmaf chain per slab, slabs in a per-workgroup rotated order).
-template <int TJ>
-__global__ void __launch_bounds__(256) gemm_nt_f32_wide_kernel(const float* __restrict__ P, int ldp,
-                                                              const float* __restrict__ Q, int ldq,
-                                                              float* __restrict__ out, int ldo, int NP,
-                                                              int NQ, int K, const float* __restrict__ qsub,
-                                                              const float* __restrict__ bias,
-                                                              const float* __restrict__ alpha, int tiles_i) {
-    constexpr int BI = 128, BJ = 32 * TJ, KS = 128;       // rows of P / Q per tile, floats per slab
-    constexpr int RB = KS * 4;                             // 512-byte LDS rows
-    constexpr int NPV = BI * (RB / 16) / 256;              // 16 loads per lane for P
-    constexpr int NQV = BJ * (RB / 16) / 256;              // 4 * TJ for Q
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // (BI + BJ) * 512 bytes
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_i = wg % tiles_i, tile_j = wg / tiles_i;
-    const int i0 = tile_i * BI, j0 = tile_j * BJ;
-
-    // staging: 32 consecutive lanes cover one row's 512 bytes; load v takes row v * 8 + tid / 32
-    const int srow = tid >> 5, schunk = tid & 31;
-    f32x4_t pr[NPV], qr[NQV];
-    auto fetch = [&](int k0) {
-        const int k = k0 + schunk * 4;                     // K % 128 == 0: a slab is never ragged
-#pragma unroll
-        for (int v = 0; v < NPV; ++v) {
-            const int row = i0 + v * 8 + srow;
-            f32x4_t x = {0.f, 0.f, 0.f, 0.f};
-            if (row < NP) x = *(const DIR_GLOBAL f32x4_t*)(P + (size_t)row * ldp + k);
-            pr[v] = x;
-        }
-        f32x4_t sub = {0.f, 0.f, 0.f, 0.f};
-        if (qsub) sub = *(const DIR_GLOBAL f32x4_t*)(qsub + k);
-#pragma unroll
-        for (int v = 0; v < NQV; ++v) {
-            const int row = j0 + v * 8 + srow;
-            f32x4_t x = {0.f, 0.f, 0.f, 0.f};
-            if (row < NQ) x = *(const DIR_GLOBAL f32x4_t*)(Q + (size_t)row * ldq + k) - sub;
-            qr[v] = x;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int v = 0; v < NPV; ++v) {
-            const int row = v * 8 + srow;
-            *(f32x4_t*)(smem + row * RB + ((schunk ^ (row & 15)) << 4)) = pr[v];
-        }
-#pragma unroll
-        for (int v = 0; v < NQV; ++v) {
-            const int row = v * 8 + srow;
-            *(f32x4_t*)(smem + (BI + row) * RB + ((schunk ^ (row & 15)) << 4)) = qr[v];
-        }
-    };
-
-    const int lrow = lane & 31, lhi = lane >> 5;
-    f32x16_t acc[TJ];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-
-    // lane (row i = lrow, k half h = lhi): chunk 2c + h of its row holds k = 8c + 4h .. + 3
-    const char* const prow = smem + (wave * 32 + lrow) * RB;
-    const int pswz = (wave * 32 + lrow) & 15;
-    auto compute = [&]() {
-#pragma unroll 4
-        for (int c = 0; c < KS / 8; ++c) {
-            const int chunk = 2 * c + lhi;
-            const f32x4_t pf = *(const f32x4_t*)(prow + ((chunk ^ pswz) << 4));
-            f32x4_t qf[TJ];
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int qrow = j * 32 + lrow;
-                qf[j] = *(const f32x4_t*)(smem + (BI + qrow) * RB + ((chunk ^ (qrow & 15)) << 4));
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[q], qf[j][q], acc[j], 0, 0, 0);
-        }
-    };
-
-    const int T = K / KS;
-    const int rot = (int)(((unsigned)tile_i * 7u + (unsigned)tile_j * 3u) % (unsigned)T);
-    auto slab = [&](int t) {
-        int u = t + rot;
-        if (u >= T) u -= T;
-        return u * KS;
-    };
-    fetch(slab(0));
-    commit();
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const bool more = t + 1 < T;
-        if (more) fetch(slab(t + 1));      // in flight underneath this slab's 192 MFMAs per wave
-        compute();
-        __syncthreads();                   // every wave is done reading the buffer
-        if (more) {
-            commit();
-            __syncthreads();
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int jj = j0 + j * 32 + lrow;
-        if (jj >= NQ) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ii = i0 + wave * 32 + 8 * g + 4 * lhi;
-            float v[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ii + e < NP) {
-                    float r = v[e];
-                    if (alpha) r *= alpha[ii + e];
-                    if (bias) r += bias[ii + e];
-                    v[e] = r;
-                }
-            }
-            float* dst = out + (size_t)jj * ldo + ii;
-            if (ii + 3 < NP && ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0)) {
-                *(DIR_GLOBAL f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (ii + e < NP) dst[e] = v[e];
-            }
-        }
-    }
-}
-
 // Few Q rows (batch-sized FC: NQ <= 32): the MFMA tiling would leave 240 of 256 CUs idle, and the
 // job is a pure stream of P (NP*K*4 bytes, read once).  One wave per P row: the row lives in
 // registers (K/64 floats per lane, coalesced float4 loads), the NQ small Q rows come from L2, each
@@ -398,29 +252,6 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
     const int vec_ok = !(K & 3) && !(ldp & 3) && !(ldq & 3) && !((uintptr_t)P & 15) && !((uintptr_t)Q & 15) &&
                        !(qsub && ((uintptr_t)qsub & 15));
     const int tiles_i = ceil_div(NP, 128);
-    // long P against a query-sized Q with 16-byte friendly rows: the 512-byte-slab kernel (config D)
-    static const bool no_wide = getenv("DIRTORCH_AMD_NO_WIDE_GEMM") != nullptr;     // A/B and bisecting
-    if (vec_ok && !no_wide && K % 128 == 0 && K >= 256 && NQ <= 128 && NP >= 32768) {
-        const int tjw = NQ >= 97 ? 4 : (NQ >= 65 ? 3 : (NQ >= 33 ? 2 : 1));
-        const int lds = (128 + 32 * tjw) * 512;
-#define DIR_GW(TJ)                                                                                        \
-    do {                                                                                                  \
-        static std::atomic<uint64_t> done{0};                                                             \
-        if (hipError_t e = ensure_dynamic_lds((const void*)gemm_nt_f32_wide_kernel<TJ>, lds, done); e != hipSuccess) \
-            return fail(DIR_ERR_HIP, std::string("gemm_nt_f32: ") + hipGetErrorString(e));                \
-        hipLaunchKernelGGL(gemm_nt_f32_wide_kernel<TJ>, dim3((unsigned)tiles_i), dim3(256), lds, stream, P, ldp, \
-                           Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, tiles_i);                      \
-    } while (0)
-        switch (tjw) {
-            case 1: DIR_GW(1); break;
-            case 2: DIR_GW(2); break;
-            case 3: DIR_GW(3); break;
-            default: DIR_GW(4); break;
-        }
-#undef DIR_GW
-        DIR_HIP_CHECK(hipGetLastError());
-        return DIR_OK;
-    }
     // Q tile: as wide as needed up to 128 rows, then loop tiles over j.
     int tj = NQ >= 97 ? 4 : (NQ >= 65 ? 3 : (NQ >= 33 ? 2 : 1));
     const int tiles_j = ceil_div(NQ, 32 * tj);
