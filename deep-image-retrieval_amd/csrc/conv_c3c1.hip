@@ -346,13 +346,7 @@ static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.x_bytes = (uint32_t)((size_t)a.M * a.Cin * 2);
     const int mt = (a.M + 63) / 64;
-    int ncu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            ncu = prop.multiProcessorCount;
-    }
+    const int ncu = cu_count();
     hipLaunchKernelGGL(kern, dim3(mt < ncu ? mt : ncu), dim3(512), LDS, stream, b);
     return hipGetLastError();
 }

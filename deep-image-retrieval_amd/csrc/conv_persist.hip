@@ -335,13 +335,7 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     fd((uint32_t)(a.OH * a.OW), b.div_ohw_mul, b.div_ohw_shr);
     fd((uint32_t)a.OW, b.div_ow_mul, b.div_ow_shr);
     const int ntiles = b.tiles_m * b.tiles_n;
-    int ncu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            ncu = prop.multiProcessorCount;
-    }
+    const int ncu = cu_count();
     const int grid = ntiles < ncu ? ntiles : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, b);
     return hipGetLastError();

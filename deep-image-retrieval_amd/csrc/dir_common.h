@@ -128,6 +128,20 @@ __device__ inline int xcd_remap(int bid, int nwg) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// CU count of the current device, cached per device: hipGetDeviceProperties costs tens of microseconds, far too
+// much for a launcher that runs 100+ times per batch-1 forward.
+inline int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int n = cached[dev & 63].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cached[dev & 63].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 // One-time opt-in of a kernel to more than 64 KiB of dynamic LDS, PER DEVICE (one engine per GPU may
 // live in the same process) and safe against concurrent first launches from several host threads.
 inline hipError_t ensure_dynamic_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {

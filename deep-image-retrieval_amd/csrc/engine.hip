@@ -429,7 +429,9 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
     }
     if (variant < 0) variant = conv_pick_variant(a);
     a.ksplit = conv_splitk_factor(variant, a);
-    int rc = prof_begin(L.name, std::string("conv_igemm<") + conv_variant(variant).name +
+    int rc = DIR_OK;
+    if (profiling && !prof_paused)   // (the label strings are only built when somebody will read them)
+        rc = prof_begin(L.name, std::string("conv_igemm<") + conv_variant(variant).name +
                                     (a.ksplit > 1 ? "/k" + std::to_string(a.ksplit) : "") + ">",
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
@@ -445,8 +447,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     *used = 0;
     // DIRTORCH_AMD_C3C1: "0" = never (A/B and bisecting), "force" = whenever the shapes qualify, default =
     // when every persistent workgroup gets at least ~4 pixel tiles to amortise loading both weight sets
-    const char* mode = getenv("DIRTORCH_AMD_C3C1");   // read per call: tests toggle it
-    if (mode && mode[0] == '0') return DIR_OK;
+    if (sw.c3c1_off) return DIR_OK;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = t2;
@@ -481,13 +482,14 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.relu2 = c1.relu ? 1 : 0;
     if (c1.R != 1 || c1.S != 1 || c1.stride != 1 || c1.pad != 0 || c1.Cin != c3.Cout || !conv_c3c1_admissible(a))
         return DIR_OK;
-    const bool force = mode && mode[0] == 'f';
-    if (!force && (a.M + 63) / 64 < 1024) return DIR_OK;
+    if (!sw.c3c1_force && (a.M + 63) / 64 < 1024) return DIR_OK;
     const double macs = (double)a.M * ((double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
     const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
                                 (double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
     // profile row "layerS.J.c3c1": conv3 of block J + conv1 of block J+1
-    int rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + (block_in ? ".ds+c3c1" : ".c3c1"),
+    int rc = DIR_OK;
+    if (profiling && !prof_paused)
+        rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + (block_in ? ".ds+c3c1" : ".c3c1"),
                         "conv_c3c1<" + std::to_string(c3.Cin) + (block_in ? ",ds>" : ">"),
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
@@ -502,7 +504,7 @@ int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t
                               uint16_t* y, int B, int Hin, int Win, int OH, int OW, hipStream_t stream, int* used,
                               bool dry) {
     *used = 0;
-    if (!c3.d_w_ds || getenv("DIRTORCH_AMD_NO_DUAL")) return DIR_OK;      // (env: A/B and bisecting)
+    if (!c3.d_w_ds || sw.no_dual) return DIR_OK;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = t2;
@@ -531,7 +533,9 @@ int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t
     if (dry) return DIR_OK;
     const double macs = (double)a.M * c3.Cout * (double)a.Ktot;
     const double bytes = 2.0 * ((double)a.M * (c3.Cin + ds.Cin + c3.Cout) + (double)c3.Cout * a.Ktot);
-    int rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".ds+conv3",
+    int rc = DIR_OK;
+    if (profiling && !prof_paused)
+        rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".ds+conv3",
                         std::string("conv_igemm<") + conv_variant(variant).name + "/dual>", 2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     rc = conv_launch(a, dtype, variant, stream);
@@ -549,6 +553,15 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     if (cur_dev != device)   // the weights live on `device`; launching elsewhere would fault
         return fail(DIR_ERR_STATE, "forward: the current HIP device (" + std::to_string(cur_dev) +
                                        ") is not the engine's device (" + std::to_string(device) + ")");
+    {   // DIRTORCH_AMD_C3C1: "0" = never use the fused seam kernel, "force" = whenever the shapes qualify,
+        // default = when every persistent workgroup gets >= ~4 pixel tiles; the NO_* switches restore the
+        // separate downsample launch (A/B and bisecting; results equal up to 16-bit rounding)
+        const char* mode = getenv("DIRTORCH_AMD_C3C1");
+        sw.c3c1_off = mode && mode[0] == '0';
+        sw.c3c1_force = mode && mode[0] == 'f';
+        sw.no_ds_seam = getenv("DIRTORCH_AMD_NO_DS_SEAM") != nullptr;
+        sw.no_dual = getenv("DIRTORCH_AMD_NO_DUAL") != nullptr;
+    }
     Plan p;
     int rc = plan(B, H, W, &p);
     if (rc != DIR_OK) return rc;
@@ -623,11 +636,8 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         bool ds_in_seam = false;
         if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds && convs[bd.conv3].Cin == 64 &&
             convs[bd.down].Cin == 64 && convs[bd.down].stride == 1) {
-            const char* mode = getenv("DIRTORCH_AMD_C3C1");
-            const bool off = mode && mode[0] == '0', force = mode && mode[0] == 'f';
-            const char* nods = getenv("DIRTORCH_AMD_NO_DS_SEAM");      // A/B and bisecting
             // (oversized batches are left to conv_launch's own 2^31-byte error)
-            ds_in_seam = !off && !nods && (force || ((long)B * oh * ow + 63) / 64 >= 1024) &&
+            ds_in_seam = !sw.c3c1_off && !sw.no_ds_seam && (sw.c3c1_force || ((long)B * oh * ow + 63) / 64 >= 1024) &&
                          (long)B * oh * ow * convs[bd.conv3].Cout < (1L << 30);
         }
         // the other stages' first blocks: conv3 + downsample as one two-source GEMM (conv_igemm.hip, DUAL)
