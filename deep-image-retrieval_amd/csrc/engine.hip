@@ -441,12 +441,17 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
 }
 
 // ---- fused bottleneck seam ----------------------------------------------------------------------------
+// The persistent seam kernel pays for loading both weight sets into registers once per workgroup: it wins from
+// about 8 pixel tiles of 64 per workgroup (A/B at 1024^2: batch 1 = 1024 tiles: -2 %, batch 2: equal, batch 4:
+// +4 %, batch 32: +6 %).
+static constexpr long kSeamMinTiles = 2048;
+
 int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
                          uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
                          const uint16_t* block_in) {
     *used = 0;
     // DIRTORCH_AMD_C3C1: "0" = never (A/B and bisecting), "force" = whenever the shapes qualify, default =
-    // when every persistent workgroup gets at least ~4 pixel tiles to amortise loading both weight sets
+    // when every persistent workgroup gets at least ~8 pixel tiles to amortise loading both weight sets
     if (sw.c3c1_off) return DIR_OK;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -482,7 +487,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.relu2 = c1.relu ? 1 : 0;
     if (c1.R != 1 || c1.S != 1 || c1.stride != 1 || c1.pad != 0 || c1.Cin != c3.Cout || !conv_c3c1_admissible(a))
         return DIR_OK;
-    if (!sw.c3c1_force && (a.M + 63) / 64 < 1024) return DIR_OK;
+    if (!sw.c3c1_force && (a.M + 63) / 64 < kSeamMinTiles) return DIR_OK;
     const double macs = (double)a.M * ((double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
     const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
                                 (double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
@@ -637,7 +642,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds && convs[bd.conv3].Cin == 64 &&
             convs[bd.down].Cin == 64 && convs[bd.down].stride == 1) {
             // (oversized batches are left to conv_launch's own 2^31-byte error)
-            ds_in_seam = !sw.c3c1_off && !sw.no_ds_seam && (sw.c3c1_force || ((long)B * oh * ow + 63) / 64 >= 1024) &&
+            ds_in_seam = !sw.c3c1_off && !sw.no_ds_seam && (sw.c3c1_force || ((long)B * oh * ow + 63) / 64 >= kSeamMinTiles) &&
                          (long)B * oh * ow * convs[bd.conv3].Cout < (1L << 30);
         }
         // the other stages' first blocks: conv3 + downsample as one two-source GEMM (conv_igemm.hip, DUAL)

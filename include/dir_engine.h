@@ -167,7 +167,7 @@ int dir_conv_bn_act_splitk(const void* x, const void* w, const float* bias, cons
  * (dirtorch/nets/backbones/resnet.py:78-85 then :70-72); P2 = P inside a stage, P2 = 128 after P = 64 for
  * the layer1 -> layer2 boundary.  t2 [B,H,W,P], res / y [B,H,W,4P], t1 [B,H,W,P2],
  * NHWC 16-bit; conv1 consumes the ROUNDED y, so the pair equals two dir_conv_bn_act calls up to fp32
- * summation order.  The engine uses it for the layer1 / layer2 seams when the map has >= 65536 pixels. */
+ * summation order.  The engine uses it for the layer1 / layer2 seams when the map has >= 131072 pixels. */
 int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void* res, void* y, const void* w1,
                   const float* bias1, void* t1, int B, int H, int W, int P, int P2, int relu3, int relu1, int dtype,
                   void* stream);
