@@ -104,9 +104,11 @@ def layer_group(name):
 
 
 def kernel_table(prof, nprof, peak_tf, traffic):
-    """One row per (kernel, layer group, algorithmic flops, bytes): launches per step, average
-    duration, share of the step, achieved TFLOP/s and GB/s, the roof that bounds it (arithmetic
-    intensity vs 2.5 PF / 8 TB/s = 312 FLOP/B) and the fraction of that roof."""
+    """One row per (kernel, layer group, algorithmic flops, bytes): launches per step, average duration,
+    share of the step, the roof that bounds it (arithmetic intensity vs 2.5 PF / 8 TB/s = 312 FLOP/B), the
+    fraction of that roof and - where profiles/traffic.json has it - PMC HBM bytes / algorithmic bytes.
+    Returned compact ({"cols": [...], "rows": [[...], ...]}, rows below 1 % of the step folded into one) so
+    that the one JSON line stays a few KB; `--layers` prints every launch."""
     groups = {}
     total = sum(r['ms'] for r in prof)
     for r in prof:
@@ -114,25 +116,28 @@ def kernel_table(prof, nprof, peak_tf, traffic):
         g = groups.setdefault(key, [0.0, 0])
         g[0] += r['ms']
         g[1] += 1
-    rows = []
+    rows, rest = [], [0.0, 0]
     balance = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
-    for (kern, grp, fl, by), (ms, n) in groups.items():
+    for (kern, grp, fl, by), (ms, n) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+        if ms / total < 0.01:
+            rest[0] += ms
+            rest[1] += n
+            continue
         avg = ms / n
         tf = fl / (avg * 1e-3) / 1e12 if fl else 0.0
         gbs = by / (avg * 1e-3) / 1e9 if by else 0.0
         hbm = (fl / by) < balance if (fl and by) else True
-        row = {'kernel': kern, 'layers': grp, 'launches_per_step': round(n / nprof, 2), 'avg_ms': round(avg, 5),
-               'share': round(ms / total, 4), 'gflop': round(fl / 1e9, 2), 'mbytes': round(by / 1e6, 1),
-               'tflops': round(tf, 1), 'gbs': round(gbs, 1), 'bound': 'hbm' if hbm else 'mfma',
-               'frac': round(gbs / PEAK_HBM_GBS if hbm else tf / peak_tf, 4)}
         t = (traffic or {}).get(kern)
         if isinstance(t, dict):          # per-shape PMC traffic keyed by layer group (scripts/summarize_prof.py)
             t = t.get(grp)
-        if t and by:
-            row['pmc_traffic_ratio'] = round(t / by, 3)
-        rows.append(row)
-    rows.sort(key=lambda r: -r['share'])
-    return rows
+        rows.append([kern.replace('conv_igemm<', '').rstrip('>') if kern.startswith('conv_igemm<') else kern, grp,
+                     round(n / nprof, 1), round(avg, 4), round(ms / total, 3), 'hbm' if hbm else 'mfma',
+                     round(gbs / PEAK_HBM_GBS if hbm else tf / peak_tf, 3), round(t / by, 2) if (t and by) else None])
+    if rest[1]:
+        rows.append(['(others)', '', round(rest[1] / nprof, 1), round(rest[0] / rest[1], 4), round(rest[0] / total, 3),
+                     None, None, None])
+    return {'cols': ['kernel', 'layers', 'launches_per_step', 'avg_ms', 'share', 'bound', 'frac_of_bound',
+                     'pmc_traffic_ratio'], 'rows': rows}
 
 
 def main():
@@ -255,8 +260,7 @@ def main():
                 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                 'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / peak_tf, 4),
                 'traffic': traffic,
-                'note': 'frac is the largest-time-share kernel against ITS roof; the whole step is step_mfma_frac of '
-                        'the dense MFMA peak (per-kernel rows in kernels[])',
+                'note': 'frac = the largest-time-share kernel against ITS roof; whole step = step_mfma_frac of the MFMA peak',
                 'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
                 'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
                 'kernel_tflops': round(tflops, 2), 'kernel_gbs': round(gbs, 1),

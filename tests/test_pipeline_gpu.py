@@ -317,3 +317,80 @@ def test_bucketed_batching_keeps_order_and_values(tmp_path, monkeypatch):
     ref = oracle_descriptors(O.synth_state_dict('resnet18', seed=7, gemp=3.0), 'resnet18',
                              [str(tmp_path / 'imgs' / n) for n in names])
     assert float((1 - (a * ref).sum(1)).max()) < 1e-4
+
+
+def test_eval_model_with_query_expansion_and_db_augmentation(tmp_path, monkeypatch):
+    """test_dir.eval_model(..., aqe=, adba=) from saved features (--load-feats): whitening -> alpha-DBA of the
+    database -> alpha-QE of the queries against the augmented database -> similarity -> AP, every step on the
+    GPU, against the oracle's restatement of the same chain (expand_descriptors pinned to the reference's
+    outputs in tests/test_oracle_golden.py).  The reference reads `args.adba / args.aqe` from a module global
+    inside eval_model (test_dir.py:141,143); the function parameters are what is meant."""
+    import dir_oracle as O
+    import synth
+    from dirtorch_amd import datasets
+    from dirtorch_amd import test_dir as td
+    N, Q, D = 300, 12, 256
+    r = np.random.RandomState(3)
+    gnd = []
+    for q in range(Q):
+        idx = r.choice(np.arange(Q, N), 14, replace=False)
+        gnd.append({'bbx': [0, 0, 1, 1], 'easy': sorted(idx[:5].tolist()), 'hard': sorted(idx[5:10].tolist()),
+                    'junk': sorted(idx[10:].tolist())})
+    f = str(tmp_path / 'gnd.pkl')
+    with open(f, 'wb') as fh:
+        pickle.dump({'imlist': ['i%d' % i for i in range(N)], 'qimlist': ['q%d' % i for i in range(Q)], 'gnd': gnd}, fh)
+    db = datasets.ImageListRelevants(f, root=str(tmp_path))
+    bdescs = synth.synth_descriptors(51, N, D, clusters=20)
+    qdescs = synth.synth_descriptors(52, Q, D, clusters=20)
+    for q in range(Q):                      # plant the positives near their query
+        for j in gnd[q]['easy'] + gnd[q]['hard']:
+            v = bdescs[j] * 0.6 + qdescs[q]
+            bdescs[j] = v / np.linalg.norm(v)
+    feats = tmp_path / 'feats'
+    feats.mkdir()
+    np.save(str(feats / 'feats.bdescs.npy'), bdescs)
+    np.save(str(feats / 'feats.qdescs.npy'), qdescs)
+    pca = O.fit_pca(bdescs)
+
+    class Net(object):                      # eval_model only reads net.pca on the --load-feats path
+        pass
+    net = Net()
+    net.pca = pca
+    whiten = dict(whitenp=0.25, whitenv=64, whitenm=1.0)
+    res = td.eval_model(db, net, '', whiten=whiten, aqe={'k': 3, 'alpha': 2}, adba={'k': 4, 'alpha': 1},
+                        load_feats=str(feats), detailed=True)
+    b = O.whiten_features(bdescs, pca, **whiten)
+    q = O.whiten_features(qdescs, pca, **whiten)
+    b = O.expand_descriptors(b, alpha=1, k=4)
+    q = O.expand_descriptors(q, db=b, alpha=2, k=3)
+    ref = O.mean_ap(O.matmul(q, b), gnd)
+    for k in ref:
+        assert abs(res[k] - ref[k]) < 1e-9, (k, res[k], ref[k])
+    plain = td.eval_model(db, net, '', whiten=whiten, load_feats=str(feats))
+    assert any(abs(plain[k] - res[k]) > 1e-6 for k in ref)      # the expansion actually changed the ranking
+
+
+def test_fp16_overflow_is_reported_not_returned(tmp_path):
+    """Activations that leave the fp16 range turn into inf/NaN descriptors; the extraction loops must say so
+    (and name the bf16 switch) instead of handing them on.  A checkpoint with a huge BatchNorm gain does it."""
+    import dir_oracle as O
+    from dirtorch_amd import datasets, nets
+    from dirtorch_amd import test_dir as td
+    names = ['a.png', 'b.png']
+    save_images(str(tmp_path / 'imgs'), names, [(64, 64), (64, 64)], 7)
+    (tmp_path / 'list.txt').write_text('\n'.join(names) + '\n')
+    db = datasets.create('ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'))
+    sd = O.synth_state_dict('resnet18', seed=7, gemp=3.0)
+    sd['layer2.0.bn2.weight'] = sd['layer2.0.bn2.weight'] * 1e6
+    for dtype, ok in (('fp16', False), ('bf16', True)):
+        net = nets.create_model('resnet18_rmac', pretrained='')
+        net.load_state_dict(sd)
+        net.compute_dtype = dtype
+        net.cuda().eval()
+        if ok:
+            d = td.extract_image_features(db, '', net, threads=0)
+            assert torch.isfinite(d).all()
+        else:
+            with pytest.raises(FloatingPointError) as ei:
+                td.extract_image_features(db, '', net, threads=0)
+            assert 'DIRTORCH_AMD_DTYPE=bf16' in str(ei.value)
