@@ -583,6 +583,9 @@ int conv_pick_variant(const ConvArgs& a) {
         c[n++] = {"128x256_w2x4_s3_k32", 2}, c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};   // short K: more, smaller tiles
     } else {
+        // strided 3x3 (the first conv2 of layer2): the gather touches every other pixel, so the 128-B K rows of
+        // the BK = 64 tile halve the number of requests per byte (A/B gpurun_out/r2t: 273 -> 224 us)
+        if (a.R * a.S > 1 && a.stride > 1) c[n++] = {"256x128_w4x2_s3", 1};
         c[n++] = {"256x128_w4x2_s3_k32", 2}, c[n++] = {"128x128_w2x2", 1};
         c[n++] = {T >= 8 ? "64x128_w2x2_s4" : "64x128_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     }

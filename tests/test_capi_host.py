@@ -133,5 +133,7 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     for name, want in batch1.items():
         assert pick(1, *shapes[name]) == want, name
     # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
+    # the strided 3x3 of layer2.0 (256^2 -> 128^2): the BK = 64 tile
+    assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_w4x2_s3', 1)
     assert pick(32, 64, 256, 1024, 1, 1, 0)[0] != '64x512_wreg1x1'
     assert pick(2, 64, 256, 1024, 1, 1, 1)[0] != '64x512_wreg1x1'
