@@ -30,5 +30,10 @@ int expand_descriptors(const float* descs, int n, const float* db, int m, int D,
 int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
                 int NQ, int K, const float* qsub, const float* bias, const float* alpha,
                 hipStream_t stream);
+// large-database similarity on the bf16 matrix cores at fp32 accuracy (sim_split.hip)
+size_t similarity_split_workspace_bytes(int NQ, int K);
+bool similarity_split_admissible(const float* P, int ldp, const float* Q, int ldq, int NP, int NQ, int K);
+int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP, int NQ, int K,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace dir

@@ -1,0 +1,230 @@
+// sim_split.hip — the Q x N similarity against a LARGE database on the bf16 matrix cores, at fp32 accuracy (gfx950).
+//
+//   scores[q][n] = sum_k queries[q][k] * database[n][k]          (dirtorch/utils/common.py:30-38, test_dir.py:150)
+//
+// The exact kernel (gemm_f32.hip, v_mfma_f32_32x32x2_f32) is bound by the fp32 MFMA rate: 70 queries pad to 96 rows
+// and 2 * 96 * N * K FLOP at 157 TFLOP/s is 2.5 ms for the 1 006 322 x 2048 database of BASELINE config D before a
+// single stall, against 1.3 ms to stream the 8.2 GB once.  Here every fp32 operand is split into three bf16 planes
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (round to nearest even; the two
+//                                                                              subtractions are exact in fp32)
+// and the product is assembled from the six plane products of weight >= 2^-16,
+//     x*y ~= h*h' + (h*m' + m*h') + (h*l' + l*h' + m*m'),
+// each an exact fp32 number inside v_mfma_f32_32x32x16_bf16; the leading product and the five corrections are
+// summed in two fp32 accumulators that meet once at the end (fewer and smaller roundings than a K-long fmaf chain).  What is dropped
+// (m*l' + l*m' + l*l') is below 2^-23 |x*y| per term - under the half-ulp an fp32 product rounds by - at 6/16 of the
+// fp32 MFMA time.  Same exponent range as fp32 (bf16 keeps all 8 exponent bits), so no scaling is needed and the
+// kernel takes any fp32 matrices, not just unit vectors.  The result differs from the exact kernel the way a
+// different summation order does (~1e-7 on unit vectors); callers that need the k-ordered fmaf chain keep
+// gemm_nt_f32 (small N, or DIRTORCH_AMD_SIM_EXACT=1).
+//
+// Work split: one 512-thread workgroup per 256 database rows, one 32-row strip per wave against all 96 query rows
+// (3 accumulator blocks).  The database is used by exactly one wave, so it goes HBM -> LDS as raw fp32 by LDS-DMA
+// (128-byte pieces, XOR-swizzled rows) and is split in registers right before the MFMAs; the query planes are split
+// once by split_queries_kernel into an image that is byte-for-byte the LDS layout of every K slab (18 KB per 32
+// k), so their re-streaming from L2 is a linear copy.  Three stages of (32 KB database + 18 KB query planes) in LDS,
+// two in flight; one barrier per K slab.  Algorithmic bytes per launch: N*K*4 (database, once) + Q*N*4 (scores).
+#include "dir_common.h"
+
+namespace dir {
+
+static constexpr int kQB = 96;                    // query rows per block (3 MFMA row blocks)
+static constexpr int kPlane = kQB * 64;           // bytes of one bf16 plane of a 32-wide K slab
+static constexpr int kSlabQ = 3 * kPlane;         // 18432
+static constexpr int kRowsP = 256;                // database rows per workgroup
+static constexpr int kSlabP = kRowsP * 128;       // 32768
+static constexpr int kStage = kSlabP + kSlabQ;    // 51200
+static constexpr int kStages = 3;
+static constexpr int kLds = kStages * kStage;     // 153600 of 163840
+
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
+}
+
+// x0, x1 -> packed bf16 planes (low half = x0)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    float a, b;
+    h = BF16::pack(x0, x1);
+    BF16::unpack(h, a, b);
+    x0 -= a, x1 -= b;
+    m = BF16::pack(x0, x1);
+    BF16::unpack(m, a, b);
+    x0 -= a, x1 -= b;
+    l = BF16::pack(x0, x1);
+}
+
+// Query planes as an image of the LDS stages: [query block][K slab of 32][plane h, m, l][96 rows][64 bytes], the
+// four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3.  Rows past NQ and k past K are zero.
+__global__ void __launch_bounds__(256) split_queries_kernel(const float* __restrict__ Q, int ldq, int NQ, int K,
+                                                           uint16_t* __restrict__ img) {
+    const int t = blockIdx.x, qb = blockIdx.y, T = gridDim.x;
+    char* dst = (char*)img + ((size_t)qb * T + t) * kSlabQ;
+    for (int item = threadIdx.x; item < kQB * 4; item += 256) {
+        const int row = item >> 2, pos = item & 3;
+        const int chunk = pos ^ ((row >> 2) & 3);
+        const int q = qb * kQB + row;
+        u32x4_t h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = t * 32 + chunk * 8 + 2 * e;
+            const float x0 = (q < NQ && k < K) ? Q[(size_t)q * ldq + k] : 0.f;
+            const float x1 = (q < NQ && k + 1 < K) ? Q[(size_t)q * ldq + k + 1] : 0.f;
+            uint32_t a, b, c;
+            split2(x0, x1, a, b, c);
+            h[e] = a, m[e] = b, l[e] = c;
+        }
+        *(u32x4_t*)(dst + 0 * kPlane + row * 64 + pos * 16) = h;
+        *(u32x4_t*)(dst + 1 * kPlane + row * 64 + pos * 16) = m;
+        *(u32x4_t*)(dst + 2 * kPlane + row * 64 + pos * 16) = l;
+    }
+}
+
+__global__ void __launch_bounds__(512) sim_split_kernel(const float* __restrict__ P, int ldp, int NP, int K,
+                                                       const uint16_t* __restrict__ img, float* __restrict__ out,
+                                                       int ldo, int NQ, int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int tile = blockIdx.x, qb = blockIdx.y;
+    const int i0 = tile * kRowsP;
+    const int rows = min(kRowsP, NP - i0);
+
+    // the database can exceed the 4 GB a buffer descriptor spans: one descriptor per workgroup, based at its rows
+    const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(P + (size_t)i0 * ldp), 0, (int)((((size_t)rows - 1) * ldp + K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)img + (size_t)qb * T * kSlabQ), 0, T * kSlabQ, 0x00020000);
+
+    // database: instruction j = i * 8 + wave covers rows 8j .. 8j+7 (8 lanes x 16 bytes = one 128-byte piece)
+    uint32_t pvoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        pvoff[i] = (uint32_t)row * (uint32_t)ldp * 4u + (uint32_t)chunk * 16u;   // rows past `rows`: out of range -> 0
+    }
+    const uint32_t qvoff = (uint32_t)(wave * (kSlabQ / 8) + lane * 16);          // 2304 bytes per wave: 2 + 1/4 instr.
+
+    auto issue = [&](int u, char* stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16s(rsrc_p, stage + (i * 8 + wave) * 1024, pvoff[i], (uint32_t)u * 128u);
+        char* qd = stage + kSlabP + wave * (kSlabQ / 8);
+        dma16s(rsrc_q, qd, qvoff, (uint32_t)u * kSlabQ);
+        dma16s(rsrc_q, qd + 1024, qvoff + 1024, (uint32_t)u * kSlabQ);
+        if (lane < 16) dma16s(rsrc_q, qd + 2048, qvoff + 2048, (uint32_t)u * kSlabQ);
+    };
+    constexpr int kOps = 7;   // LDS-DMA instructions per wave per stage
+
+    f32x16_t acc[3], lo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f, lo[j][e] = 0.f;
+
+    const int boff = (wave * 32 + lrow) * 128, bswz = (lrow >> 1) & 7;
+    const int aoff = kSlabP + lrow * 64, aswz = (lrow >> 2) & 3;
+
+    auto compute = [&](const char* stage) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c0 = s * 4 + lhi * 2;
+            const f32x4_t b0 = *(const f32x4_t*)(stage + boff + ((c0 ^ bswz) << 4));
+            const f32x4_t b1 = *(const f32x4_t*)(stage + boff + (((c0 + 1) ^ bswz) << 4));
+            u32x4_t ah[3], am[3], al[3];
+            const int ach = ((s * 2 + lhi) ^ aswz) << 4;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ah[j] = *(const u32x4_t*)(stage + aoff + 0 * kPlane + j * 2048 + ach);
+                am[j] = *(const u32x4_t*)(stage + aoff + 1 * kPlane + j * 2048 + ach);
+                al[j] = *(const u32x4_t*)(stage + aoff + 2 * kPlane + j * 2048 + ach);
+            }
+            u32x4_t bh, bm, bl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h, m, l;
+                split2(e < 2 ? b0[2 * e] : b1[2 * e - 4], e < 2 ? b0[2 * e + 1] : b1[2 * e - 3], h, m, l);
+                bh[e] = h, bm[e] = m, bl[e] = l;
+            }
+#define DIR_MM(ACC, A, B)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(         \
+        __builtin_bit_cast(bf16x8_t, A[j]), __builtin_bit_cast(bf16x8_t, B), ACC[j], 0, 0, 0)
+            // the five correction products (weight <= 2^-8) have their own accumulator: the leading sum then sees
+            // K/16 roundings instead of 6K/16, and the corrections round at 2^-8 of its scale
+            DIR_MM(lo, al, bh);
+            DIR_MM(lo, ah, bl);
+            DIR_MM(lo, am, bm);
+            DIR_MM(lo, am, bh);
+            DIR_MM(lo, ah, bm);
+            DIR_MM(acc, ah, bh);
+#undef DIR_MM
+        }
+    };
+
+    // every workgroup walks K from its own starting slab: with an 8 KiB row pitch workgroups in lock-step would
+    // all be on the same few HBM channels at any instant (same rotation as gemm_nt_f32_kernel; the sum is the same)
+    const int rot = (int)(((unsigned)tile * 7u) % (unsigned)T);
+    auto slab = [&](int t) {
+        int u = t + rot;
+        return u >= T ? u - T : u;
+    };
+    issue(slab(0), smem);
+    if (T > 1) issue(slab(1), smem + kStage);
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kOps) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // slab t landed everywhere; everyone is past slab t-1, whose slot is free
+        int nxt = cur + 2;
+        if (nxt >= kStages) nxt -= kStages;
+        if (t + 2 < T) issue(slab(t + 2), smem + nxt * kStage);
+        compute(smem + cur * kStage);
+        cur = cur + 1 == kStages ? 0 : cur + 1;
+    }
+
+    // D[i][j]: lane holds database row j = lane & 31 of the strip, query rows i = 8g + 4(lane >> 5) + e
+    const int n = i0 + wave * 32 + lrow;
+    if (n < NP) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = qb * kQB + j * 32 + 8 * g + 4 * lhi + e;
+                    if (q < NQ) out[(size_t)q * ldo + n] = acc[j][4 * g + e] + lo[j][4 * g + e];
+                }
+    }
+}
+
+size_t similarity_split_workspace_bytes(int NQ, int K) {
+    return (size_t)ceil_div(NQ, kQB) * (size_t)ceil_div(K, 32) * kSlabQ;
+}
+
+bool similarity_split_admissible(const float* P, int ldp, const float* Q, int ldq, int NP, int NQ, int K) {
+    (void)Q, (void)ldq;
+    return NP > 0 && NQ > 0 && K > 0 && (K % 32) == 0 && (ldp % 4) == 0 && ((uintptr_t)P & 15) == 0 &&
+           (size_t)ldp * 4 * kRowsP < (1ull << 31) && (size_t)ceil_div(K, 32) * kSlabQ < (1ull << 31) &&
+           ceil_div(NQ, kQB) < 65536;
+}
+
+int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP, int NQ, int K,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!similarity_split_admissible(P, ldp, Q, ldq, NP, NQ, K))
+        return fail(DIR_ERR_INVALID, "similarity_split: needs K % 32 == 0, ldp % 4 == 0 and a 16-byte aligned database");
+    if (ldp < K || ldq < K || ldo < NP) return fail(DIR_ERR_INVALID, "similarity_split: ldp, ldq >= K and ldo >= NP");
+    if (!workspace || workspace_bytes < similarity_split_workspace_bytes(NQ, K))
+        return fail(DIR_ERR_WORKSPACE, "similarity_split: workspace too small");
+    if (((uintptr_t)workspace & 15) != 0) return fail(DIR_ERR_INVALID, "similarity_split: workspace must be 16-byte aligned");
+    static std::atomic<uint64_t> attr_done{0};
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_kernel, kLds, attr_done));
+    const int T = K / 32, qblocks = ceil_div(NQ, kQB);
+    hipLaunchKernelGGL(split_queries_kernel, dim3(T, qblocks), dim3(256), 0, stream, Q, ldq, NQ, K, (uint16_t*)workspace);
+    hipLaunchKernelGGL(sim_split_kernel, dim3(ceil_div(NP, kRowsP), qblocks), dim3(512), kLds, stream, P, ldp, NP, K,
+                       (const uint16_t*)workspace, out, ldo, NQ, T);
+    DIR_HIP_CHECK(hipGetLastError());
+    return DIR_OK;
+}
+
+}  // namespace dir

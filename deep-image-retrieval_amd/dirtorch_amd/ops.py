@@ -225,6 +225,26 @@ def gemm_nt(P, Q, qsub=None, bias=None, alpha=None):
     return out
 
 
+def similarity(queries, database):
+    """scores [Q, N] = queries . database^T, fp32 (dir_similarity).  Databases of >= 32768 rows with a width that
+    is a multiple of 32 run as a three-plane bf16 split on the matrix cores (products to 2^-23, fp32
+    accumulation; csrc/sim_split.hip), everything else - and everything under DIRTORCH_AMD_SIM_EXACT=1 - as
+    the k-ordered fp32 MFMA chain of gemm_nt."""
+    _need_cuda(queries, database)
+    for t in (queries, database):
+        if t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
+            raise TypeError('contiguous 2-D float32 tensors expected')
+    Q, D = queries.shape
+    N, D2 = database.shape
+    if D != D2:
+        raise ValueError('inner dimensions differ')
+    out = torch.empty(Q, N, dtype=torch.float32, device=database.device)
+    if Q == 0 or N == 0:
+        return out
+    call('dir_similarity', ptr(queries), Q, ptr(database), N, D, ptr(out), stream_ptr())
+    return out
+
+
 def multiscale_pool(xs, pooling='mean', gemp=3.0):
     """xs: [S,N,D] fp32 -> [N,D] (mean or signed-power mean); no final L2."""
     _need_cuda(xs)

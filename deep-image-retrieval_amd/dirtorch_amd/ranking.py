@@ -15,7 +15,7 @@ from . import ops
 def similarity_device(qdescs, bdescs):
     """Scores Q.DB^T as a CUDA tensor [Q, N] (common.matmul without the download)."""
     from .utils.common import _dev
-    return ops.gemm_nt(_dev(bdescs), _dev(qdescs))
+    return ops.similarity(_dev(qdescs), _dev(bdescs))
 
 
 def _mode_lists(groups, classic):

@@ -42,7 +42,7 @@ def matmul(A, B):
     elif typename(B) != torch.__name__:
         raise TypeError("matrices must be either numpy or torch type")
     # P = database rows (long operand, read once from HBM), Q = queries
-    scores = ops.gemm_nt(_dev(B), _dev(A))
+    scores = ops.similarity(_dev(A), _dev(B))
     return scores.cpu().numpy()
 
 

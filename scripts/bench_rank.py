@@ -46,10 +46,18 @@ def main():
     for tag, N in (('roxford5k', 4993), ('rparis6k+1M', 1006322)):
         db = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device='cuda'), dim=1)
         qs = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device='cuda'), dim=1)
-        ms, scores = timed(lambda: ops.gemm_nt(db, qs))
+        ms, scores = timed(lambda: ops.similarity(qs, db))
+        if N >= 32768:   # the exact fp32 MFMA chain on the same data, for the record
+            os.environ["DIRTORCH_AMD_SIM_EXACT"] = "1"
+            ms_exact, exact = timed(lambda: ops.similarity(qs, db))
+            del os.environ["DIRTORCH_AMD_SIM_EXACT"]
         res[tag] = {'N': N, 'similarity_ms': round(ms, 3),
                     'similarity_GBps': round(N * D * 4 / ms / 1e6, 1),
                     'similarity_TFLOPs': round(2.0 * Q * N * D / ms / 1e9, 2)}
+        if N >= 32768:
+            res[tag]['similarity_exact_fp32_ms'] = round(ms_exact, 3)
+            res[tag]['split_vs_exact_max_abs'] = float((scores - exact).abs().max())
+            del exact
         fdb = FakeDB(N, Q, np.random.RandomState(1))
         t0 = time.perf_counter()
         aps = ranking.eval_aps_device(fdb, scores)
