@@ -241,7 +241,13 @@ int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out
  *                      row L2 if l2norm != 0; scale[i] = 1 / (whitenm * explained_variance[i]^whitenp)
  *                      is computed by the caller (v floats, device), NULL = no rescaling
  *   dir_similarity     common.matmul(queries, database) (dirtorch/utils/common.py:30-38):
- *                      scores[q][n] = <queries[q], database[n]>, scores is [Q,N] with row stride N */
+ *                      scores[q][n] = <queries[q], database[n]>, scores is [Q,N] with row stride N.
+ *                      N >= 32768 with D % 32 == 0 (the 10^6-distractor protocol): every fp32 operand is split
+ *                      into three bf16 planes and the six leading plane products run on the bf16 matrix cores
+ *                      with fp32 accumulation (csrc/sim_split.hip) - products to 2^-23, measured error against
+ *                      fp64 below that of the k-ordered fp32 chain, 1.8x its speed; takes ceil(Q/96) * D * 576
+ *                      bytes of stream-ordered scratch (hipMallocAsync).  Smaller databases, other widths and
+ *                      DIRTORCH_AMD_SIM_EXACT=1 in the environment: the exact k-ordered chain of dir_gemm_nt_f32. */
 int dir_fc_l2(const float* x, int B, int K, const float* W, const float* b, int D, float* out,
               void* stream);
 int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components,
