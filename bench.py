@@ -186,6 +186,8 @@ def main():
     B, S, K, Wm = args.batch, args.size, args.steps, args.warmup
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
     x = torch.randn(B, 3, S, S, generator=g, device='cuda')       # normalised-image statistics
+    if os.environ.get('DIRTORCH_AMD_BENCH_CONST_INPUT'):            # experiment only (profiles/README.md): constant image ->
+        x.zero_()                                                   # spatially constant activations, minimal operand toggling
     D = net.out_dim
     shard = torch.empty(K * B, D, device='cuda')                  # this rank's descriptor block
 
