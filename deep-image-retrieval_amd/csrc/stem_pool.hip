@@ -180,6 +180,179 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
     }
 }
 
+// ---- persistent form ---------------------------------------------------------------------------------------
+// The one-tile-per-workgroup kernel above re-loads the whole 32 KiB filter for every 3 x 15 pooled tile (44 KB of
+// L2 -> LDS traffic in front of 0.9 us of MFMA work) and runs its phases - load, MFMA, conv tile to LDS, pool, store
+// - strictly one after the other: MfmaUtil 0.46, 0.43 ms at batch 32.  Here two workgroups per CU walk strided lists
+// of tiles with the FILTER IN REGISTERS (32 fragments = 128 VGPRs per wave, fetched once per workgroup straight in
+// MFMA operand layout), two patch buffers (the next tile's patch is in flight while this one is multiplied and
+// pooled) and the conv tile: 64 KiB of LDS.  Per tile: 16 KB of patch in, 5.8 KB of pooled pixels out, two barriers.
+template <class DT>
+__global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoolArgs a) {
+    constexpr int PTH = 3, PTW = 15;
+    constexpr int TH = 8, TW = 32;
+    constexpr int QW = TW + 3;
+    constexpr int QP = (TH + 3) * QW;
+    constexpr int PLANE = 512 * 16;
+    constexpr int PATCH = 2 * PLANE;          // 16 KiB
+    constexpr int TILE_OFF = 2 * PATCH;       // conv tile behind the two patch buffers
+    typedef typename DT::frag_t frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31;
+    const int lhi = lane >> 5;
+
+    const int tiles_x = (a.PW + PTW - 1) / PTW;
+    const int tiles_y = (a.PH + PTH - 1) / PTH;
+    const int ntiles = a.B * tiles_y * tiles_x;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+
+    // filter fragments: A operand of step (R, ks) for channel tile i = 8 K-elements of row i*32 + lrow
+    frag_t wf[4][4][2];
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                wf[R][ks][i] = __builtin_bit_cast(
+                    frag_t, gload16(a.w + (i * 32 + lrow) * 256 + R * 64 + ks * 16 + lhi * 8));
+    // the bias lives in LDS (256 B behind the conv tile) and is re-read at the top of every tile: the filter
+    // already takes half of the 256 registers a wave may have at two workgroups per CU
+    float* lbias = (float*)(smem + TILE_OFF + TH * TW * 128);
+    if (tid < 64) lbias[tid] = a.bias[tid];
+
+    auto issue_patch = [&](int tile, char* dst) {
+        int wg = tile;
+        const int tx = wg % tiles_x;
+        wg /= tiles_x;
+        const int ty = wg % tiles_y;
+        const int b = wg / tiles_y;
+        const int oy0 = 2 * ty * PTH - 1, ox0 = 2 * tx * PTW - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int P = i * 256 + tid;
+            const int plane = P >> 9, p = P & 511;
+            const int py = p / QW, px = p - py * QW;
+            const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+            const bool ok = p < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
+            const uint32_t v = ok ? (uint32_t)((((b * a.H2 + iy) * a.W2 + ix) * 16 + plane * 8) * 2) : kOOBs;
+            dma16s(rsrc_x, dst + (i * 256 + wave * 64) * 16, v, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // filter in registers, bias in LDS, before the counted waits start
+    issue_patch(tile, smem);
+    int cur = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        char* pbuf = smem + cur * PATCH;
+        // the other buffer was last read by the MFMA phase of the previous tile, which every wave left before
+        // the barrier in front of that tile's pooling
+        if (next < ntiles) {
+            issue_patch(next, smem + (cur ^ 1) * PATCH);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this tile's patch; the 4 newest ops may fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();   // patch landed everywhere; everyone is done pooling the previous tile
+
+        f32x16_t acc[2][2];   // start at the bias, like every conv kernel of this library (same fp32 order)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t b4 = *(const f32x4_t*)(lbias + i * 32 + 8 * g + 4 * lhi);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b4[e];
+            }
+#pragma unroll
+        for (int R = 0; R < 4; ++R)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                frag_t xf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int p = (wave * 2 + j + R) * QW + lrow + ks;
+                    xf[j] = *(const frag_t*)(pbuf + lhi * PLANE + p * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = DT::mfma32(wf[R][ks][i], xf[j], acc[i][j]);
+            }
+
+        int wg = tile;
+        const int tx = wg % tiles_x;
+        wg /= tiles_x;
+        const int ty = wg % tiles_y;
+        const int b = wg / tiles_y;
+        const int ph0 = ty * PTH, pw0 = tx * PTW;
+        const int oy0 = 2 * ph0 - 1, ox0 = 2 * pw0 - 1;
+        char* ctile = smem + TILE_OFF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tyy = wave * 2 + j;
+            const int oy = oy0 + tyy, ox = ox0 + lrow;
+            const bool in = (unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(acc[i][j][4 * g + e], 0.f) : 0.f;
+                    u32x2_t pk = {DT::pack(v[0], v[1]), DT::pack(v[2], v[3])};
+                    const int c = 4 * i + g;
+                    *(u32x2_t*)(ctile + (tyy * TW + lrow) * 128 + ((c ^ (lrow & 7)) << 4) + lhi * 8) = pk;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // conv tile complete; every wave is past its patch reads
+
+        for (int it = tid; it < PTH * PTW * 8; it += 256) {
+            const int c = it & 7;
+            const int pp = it >> 3;
+            const int py = pp / PTW, px = pp - py * PTW;
+            const int ph = ph0 + py, pw = pw0 + px;
+            if (ph >= a.PH || pw >= a.PW) continue;
+            float best[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int yy = 2 * py + dy, xx = 2 * px + dx;
+                    const u32x4_t v = *(const u32x4_t*)(ctile + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo, hi;
+                        DT::unpack(v[e], lo, hi);
+                        best[2 * e] = fmaxf(best[2 * e], lo);
+                        best[2 * e + 1] = fmaxf(best[2 * e + 1], hi);
+                    }
+                }
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = DT::pack(best[2 * e], best[2 * e + 1]);
+            gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, o);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pooling reads retired before the next tile's barrier
+        cur ^= 1;
+    }
+}
+
 int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
                      int OH, int OW, int dtype, hipStream_t stream) {
     if ((size_t)B * H2 * W2 * 32 >= (1ull << 31))
@@ -194,6 +367,18 @@ int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y,
     a.PW = (OW - 1) / 2 + 1;
     a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
     const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
+    if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "stem_pool: bad dtype");
+    static const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting
+    if (!v1) {
+        constexpr int LDSP = 2 * 2 * 512 * 16 + 8 * 32 * 128 + 256;   // two patch buffers + the conv tile + bias
+        const long grid = blocks < 2L * cu_count() ? blocks : 2L * cu_count();
+        if (dtype == DIR_BF16)
+            hipLaunchKernelGGL(stem_pool_persist_kernel<BF16>, dim3((unsigned)grid), dim3(256), LDSP, stream, a);
+        else
+            hipLaunchKernelGGL(stem_pool_persist_kernel<FP16>, dim3((unsigned)grid), dim3(256), LDSP, stream, a);
+        DIR_HIP_CHECK(hipGetLastError());
+        return DIR_OK;
+    }
     constexpr int LDS = 2 * 512 * 16 + 4 * 8192;  // 48 KiB >= the 32 KiB conv tile
     if (dtype == DIR_BF16)
         hipLaunchKernelGGL(stem_pool_kernel<BF16>, dim3((unsigned)blocks), dim3(256), LDS, stream, a);
