@@ -20,6 +20,7 @@
 namespace dir {
 
 static constexpr uint32_t kOOBs = 0x80000000u;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
 
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
@@ -134,15 +135,18 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int tyy = wave * 2 + j;
         const int oy = oy0 + tyy, ox = ox0 + lrow;
-        const bool in = (unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW;
+        const uint32_t inmask = ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) ? 0xffffffffu : 0u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v[4];
+                float v[4];   // ReLU as a signed-integer max on the bit pattern: negatives, -0 (and -NaN) -> +0
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(acc[i][j][4 * g + e], 0.f) : 0.f;
-                u32x2_t pk = {DT::pack(v[0], v[1]), DT::pack(v[2], v[3])};
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[i][j][4 * g + e];   // (a bit_cast straight from the vector element reads element 0)
+                    v[e] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, t), 0));
+                }
+                u32x2_t pk = {DT::pack(v[0], v[1]) & inmask, DT::pack(v[2], v[3]) & inmask};
                 const int c = 4 * i + g;  // 16-byte chunk (8 channels) of this pixel
                 *(u32x2_t*)(smem + (tyy * TW + lrow) * 128 + ((c ^ (lrow & 7)) << 4) + lhi * 8) = pk;
             }
@@ -156,27 +160,18 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
         const int py = pp / PTW, px = pp - py * PTW;
         const int ph = ph0 + py, pw = pw0 + px;
         if (ph >= a.PH || pw >= a.PW) continue;
-        float best[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) best[e] = 0.f;  // post-ReLU values: 0 is the identity of this max
+        // the tile holds post-ReLU values (>= +0): for those the 16-bit patterns of bf16 / fp16 order like unsigned
+        // integers, so the max is v_pk_max_u16 on the packed words - 4 VALU per 8 channels per tap, not 16 + 8
+        u16x8_t best = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int yy = 2 * py + dy, xx = 2 * px + dx;
-                const u32x4_t v = *(const u32x4_t*)(smem + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float lo, hi;
-                    DT::unpack(v[e], lo, hi);
-                    best[2 * e] = fmaxf(best[2 * e], lo);
-                    best[2 * e + 1] = fmaxf(best[2 * e + 1], hi);
-                }
+                best = __builtin_elementwise_max(
+                    best, *(const u16x8_t*)(smem + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4)));
             }
-        u32x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = DT::pack(best[2 * e], best[2 * e + 1]);
-        gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, o);
+        gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, __builtin_bit_cast(u32x4_t, best));
     }
 }
 
@@ -304,15 +299,18 @@ __global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoo
         for (int j = 0; j < 2; ++j) {
             const int tyy = wave * 2 + j;
             const int oy = oy0 + tyy, ox = ox0 + lrow;
-            const bool in = (unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW;
+            const uint32_t inmask = ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) ? 0xffffffffu : 0u;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(acc[i][j][4 * g + e], 0.f) : 0.f;
-                    u32x2_t pk = {DT::pack(v[0], v[1]), DT::pack(v[2], v[3])};
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = acc[i][j][4 * g + e];
+                        v[e] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, t), 0));
+                    }
+                    u32x2_t pk = {DT::pack(v[0], v[1]) & inmask, DT::pack(v[2], v[3]) & inmask};
                     const int c = 4 * i + g;
                     *(u32x2_t*)(ctile + (tyy * TW + lrow) * 128 + ((c ^ (lrow & 7)) << 4) + lhi * 8) = pk;
                 }
@@ -326,27 +324,16 @@ __global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoo
             const int py = pp / PTW, px = pp - py * PTW;
             const int ph = ph0 + py, pw = pw0 + px;
             if (ph >= a.PH || pw >= a.PW) continue;
-            float best[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) best[e] = 0.f;
+            u16x8_t best = {0, 0, 0, 0, 0, 0, 0, 0};   // packed unsigned max: see the one-tile kernel above
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int yy = 2 * py + dy, xx = 2 * px + dx;
-                    const u32x4_t v = *(const u32x4_t*)(ctile + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo, hi;
-                        DT::unpack(v[e], lo, hi);
-                        best[2 * e] = fmaxf(best[2 * e], lo);
-                        best[2 * e + 1] = fmaxf(best[2 * e + 1], hi);
-                    }
+                    best = __builtin_elementwise_max(
+                        best, *(const u16x8_t*)(ctile + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4)));
                 }
-            u32x4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = DT::pack(best[2 * e], best[2 * e + 1]);
-            gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, o);
+            gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, __builtin_bit_cast(u32x4_t, best));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pooling reads retired before the next tile's barrier
         cur ^= 1;
@@ -368,7 +355,7 @@ int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y,
     a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
     const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "stem_pool: bad dtype");
-    static const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting
+    const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting (read per launch: the tests flip it)
     if (!v1) {
         constexpr int LDSP = 2 * 2 * 512 * 16 + 8 * 32 * 128 + 256;   // two patch buffers + the conv tile + bias
         const long grid = blocks < 2L * cu_count() ? blocks : 2L * cu_count();

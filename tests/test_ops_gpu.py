@@ -221,10 +221,15 @@ def test_stem_space_to_depth_vs_7x7(hw, dname):
         check_close(y, ref, dname, 'stem %dx%d variant %d' % (H, W, variant))
 
 
+@pytest.mark.parametrize('form', ['persistent', 'one_tile_per_workgroup'])
 @pytest.mark.parametrize('dname', ['bf16', 'fp16'])
-@pytest.mark.parametrize('hw', [(37, 41), (64, 64), (30, 23), (224, 131), (9, 120)])
-def test_fused_stem_pool_vs_conv_relu_maxpool(hw, dname):
-    """stem_pool == MaxPool2d(3,2,1)(ReLU(Conv2d(3,64,7,2,3)(x) + b)) (resnet.py:158-161)."""
+@pytest.mark.parametrize('hw', [(37, 41), (64, 64), (30, 23), (224, 131), (9, 120), (1024, 400)])
+def test_fused_stem_pool_vs_conv_relu_maxpool(hw, dname, form, monkeypatch):
+    """stem_pool == MaxPool2d(3,2,1)(ReLU(Conv2d(3,64,7,2,3)(x) + b)) (resnet.py:158-161), both forms of the
+    kernel: the persistent one (filter in registers, double-buffered patches; 1024 x 400 x 2 images gives every
+    workgroup several tiles) and the one-tile-per-workgroup one behind DIRTORCH_AMD_STEM_V1."""
+    if form != 'persistent':
+        monkeypatch.setenv('DIRTORCH_AMD_STEM_V1', '1')
     ops = _ops()
     H, W = hw
     dt = DTYPES[dname]
