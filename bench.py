@@ -263,6 +263,8 @@ def main():
                 'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / peak_tf, 4),
                 'traffic': traffic,
                 'note': 'frac = the largest-time-share kernel against ITS roof; whole step = step_mfma_frac of the MFMA peak',
+                # measured once on a pool box (profiles/r02_mfma_ceiling.txt): bare register-only MFMA loop, 8 waves/CU
+                'mfma_ceiling_measured_tflops': {'random_operands': 1582, 'zero_operands': 2285},
                 'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
                 'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
                 'kernel_tflops': round(tflops, 2), 'kernel_gbs': round(gbs, 1),
