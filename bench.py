@@ -265,6 +265,7 @@ def main():
                 'note': 'frac = the largest-time-share kernel against ITS roof; whole step = step_mfma_frac of the MFMA peak',
                 # measured once on a pool box (profiles/r02_mfma_ceiling.txt): bare register-only MFMA loop, 8 waves/CU
                 'mfma_ceiling_measured_tflops': {'random_operands': 1582, 'zero_operands': 2285},
+                'hbm_ceiling_measured_gbs': {'read': 6305, 'copy_1to1': 5147},   # profiles/r02_hbm_ceiling.txt
                 'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
                 'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
                 'kernel_tflops': round(tflops, 2), 'kernel_gbs': round(gbs, 1),
