@@ -117,6 +117,7 @@ def pmc(fd, wd, out, traffic=None):
 # ---- per-kernel roofline table ---------------------------------------------------------------------
 ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
 PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
+MEASURED_TF, MEASURED_GBS = 1582.0, 6305.0   # scripts/probes/*_ceiling.hip on a pool box (profiles/r02_*_ceiling.txt)
 
 
 def bench_kernel_name(k):
@@ -220,6 +221,14 @@ def table(launches, stats_d, sq_d, fetch_d, write_d, out, traffic=None):
             '%.2f' % clk if clk is not None else '-'))
     lines.append('# step: %.1f us of engine kernels per forward, %.1f TFLOP/s = %.3f of the 2.5 PF dense MFMA peak' % (
         tot_us / nstep, tot_fl / tot_us / 1e6, tot_fl / tot_us / 1e6 / PEAK_TF))
+    # the same step against per-kernel floors max(flops / MFMA rate, bytes / HBM rate): at the guide's peaks and at the
+    # rates this pool's boxes deliver to kernels that do nothing else (profiles/r02_mfma_ceiling.txt, r02_hbm_ceiling.txt)
+    def floors(tf_rate, gb_rate):
+        return sum(g['n'] * max(k[2] / (tf_rate * 1e6), k[3] / (gb_rate * 1e3)) for k, g in groups.items() if g['n']) / nstep
+    f_peak, f_meas = floors(PEAK_TF, PEAK_GBS), floors(MEASURED_TF, MEASURED_GBS)
+    lines.append('# sum of per-kernel floors: %.1f us at 2.5 PF / 8 TB/s = %.3f of the measured step; %.1f us at the measured ceilings '
+                 '%.2f PF (random operands) / %.1f TB/s (read) = %.3f of the measured step' % (
+                     f_peak, f_peak / (tot_us / nstep), f_meas, MEASURED_TF / 1e3, MEASURED_GBS / 1e3, f_meas / (tot_us / nstep)))
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
     if traffic:
