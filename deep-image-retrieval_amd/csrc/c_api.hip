@@ -483,6 +483,9 @@ int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream) {
     DIR_CATCH
 }
 
+/* host-only: the number of K slices dir_gemm_nt_f32 runs a shape with (1 = no split) */
+int dir_gemm_splitk_factor(int NP, int NQ, int K) { return gemm_splitk_factor(NP, NQ, K); }
+
 int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
                     int NQ, int K, const float* qsub, const float* bias, const float* alpha,
                     void* stream) {

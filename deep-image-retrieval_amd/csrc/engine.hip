@@ -752,7 +752,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
                         4.0 * ((double)D * head_dim + (double)B * (head_dim + D)), stream);
         if (rc != DIR_OK) return rc;
         rc = gemm_nt_f32(d_fc_w, head_dim, pooled, head_dim, fcout, D, D, B, head_dim, nullptr,
-                         d_fc_b, nullptr, stream);
+                         d_fc_b, nullptr, stream, splitk_scratch, kSplitKMaxBytes);   // the convs are done with it
         if (rc != DIR_OK) return rc;
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
     } else {

@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
                                                          const float* __restrict__ qsub,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ alpha,
-                                                         int tiles_i, int vec_ok) {
+                                                         int tiles_i, int vec_ok, int ksplit,
+                                                         float* __restrict__ partial) {
     constexpr int BI = 128, BJ = 32 * TJ;
     constexpr int PS = BI * 128;              // bytes of one P slab (128 rows x 32 floats)
     constexpr int STAGE_BYTES = (BI + BJ) * 128;
@@ -114,21 +115,29 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
         }
     };
 
-    const int T = (K + 31) / 32;
+    // split-K (blockIdx.y = slice): few output tiles and a long K - the FC of a small batch, 16 tiles x 2048 - would
+    // leave most CUs idle; each slice writes its raw sums to partial[slice][NQ][NP], gemm_splitk_finalize_kernel adds
+    // them in slice order with alpha / bias
+    const int Tall = (K + 31) / 32;
+    const int Ts = (Tall + ksplit - 1) / ksplit;
+    const int t0 = (int)blockIdx.y * Ts;
+    const int T = min(Ts, Tall - t0);
     // Every workgroup walks K from a different starting slab (a rotation of the same sum).  With a
     // power-of-two row pitch (D = 2048 floats = 8 KiB) workgroups marching through K in lock-step
     // would all be fetching addresses congruent modulo the pitch - the same few HBM channels - at
     // any instant; staggering the phase spreads the stream over all of them.
-    const int rot = (int)(((unsigned)tile_i * 7u + (unsigned)tile_j * 3u) % (unsigned)T);
+    const int rot = T > 0 ? (int)(((unsigned)tile_i * 7u + (unsigned)tile_j * 3u) % (unsigned)T) : 0;
     auto slab = [&](int t) {
         int u = t + rot;
         if (u >= T) u -= T;
-        return u * 32;
+        return (t0 + u) * 32;
     };
     char* stage0 = smem;
     char* stage1 = smem + STAGE_BYTES;
-    fetch(slab(0));
-    commit(stage0);
+    if (T > 0) {
+        fetch(slab(0));
+        commit(stage0);
+    }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         char* cur = (t & 1) ? stage1 : stage0;
@@ -151,15 +160,16 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_kernel(const float* __restric
             float v[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (ii + e < NP) {
+                if (ii + e < NP && ksplit == 1) {
                     float r = v[e];
                     if (alpha) r *= alpha[ii + e];
                     if (bias) r += bias[ii + e];
                     v[e] = r;
                 }
             }
-            float* dst = out + (size_t)jj * ldo + ii;
-            if (ii + 3 < NP && ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0)) {
+            float* dst = ksplit == 1 ? out + (size_t)jj * ldo + ii
+                                     : partial + ((size_t)blockIdx.y * NQ + jj) * (size_t)NP + ii;
+            if (ii + 3 < NP && ksplit == 1 && ((ldo & 3) == 0) && (((uintptr_t)out & 15) == 0)) {
                 *(DIR_GLOBAL f32x4_t*)dst = (f32x4_t){v[0], v[1], v[2], v[3]};
             } else {
 #pragma unroll
@@ -228,11 +238,42 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(const float* __restr
     }
 }
 
+__global__ void __launch_bounds__(256) gemm_splitk_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                  int ldo, int NP, int NQ, int ksplit,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ alpha) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)NP * NQ) return;
+    const int j = (int)(idx / NP), i = (int)(idx - (long)j * NP);
+    float r = 0.f;
+    for (int z = 0; z < ksplit; ++z) r += partial[((size_t)z * NQ + j) * (size_t)NP + i];   // fixed order: run-to-run identical
+    if (alpha) r *= alpha[i];
+    if (bias) r += bias[i];
+    out[(size_t)j * ldo + i] = r;
+}
+
+// How many K slices the MFMA path runs for a shape (1 = no split): only when the output has too few 128 x 32TJ tiles
+// to occupy the chip and K is long enough that every slice keeps >= 4 slabs of 32.
+int gemm_splitk_factor(int NP, int NQ, int K) {
+    const int tj = NQ >= 97 ? 4 : (NQ >= 65 ? 3 : (NQ >= 33 ? 2 : 1));
+    const long tiles = (long)ceil_div(NP, 128) * ceil_div(NQ, 32 * tj);
+    const int T = ceil_div(K, 32);
+    if (tiles >= 128 || T < 16 || NQ <= 4) return 1;   // a handful of Q rows: the one-wave-per-two-rows kernel below
+    long s = 256 / tiles;
+    if (s > 16) s = 16;
+    if (s > T / 4) s = T / 4;
+    while (s > 1 && (size_t)s * NQ * NP * sizeof(float) > kGemmSplitKMaxBytes) --s;
+    return s < 2 ? 1 : (int)s;
+}
+
 int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
                 int NQ, int K, const float* qsub, const float* bias, const float* alpha,
-                hipStream_t stream) {
+                hipStream_t stream, float* scratch, size_t scratch_bytes) {
     if (NP <= 0 || NQ <= 0) return DIR_OK;
-    if (NQ <= 32 && K <= 2048 && K > 0 && !(K & 3) && !(ldp & 3) && !(ldq & 3) &&
+    // the one-wave-per-two-rows kernel re-reads every Q row from L2 for every wave: fine for a handful of Q rows,
+    // 268 MB of L2 traffic for the FC of a 32-image batch (87 us) - those go to the MFMA path with split-K
+    const bool few_q = gemm_splitk_factor(NP, NQ, K) == 1;
+    if (few_q && NQ <= 32 && K <= 2048 && K > 0 && !(K & 3) && !(ldp & 3) && !(ldq & 3) &&
         !((uintptr_t)P & 15) && !((uintptr_t)Q & 15) && !(qsub && ((uintptr_t)qsub & 15))) {
         const unsigned blocks = (unsigned)ceil_div(NP, 8);   // 4 waves x 2 rows
         if (K <= 1024)
@@ -257,9 +298,21 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
     const int tiles_j = ceil_div(NQ, 32 * tj);
     const long nblk = (long)tiles_i * tiles_j;
     if (nblk >= (1L << 31)) return fail(DIR_ERR_INVALID, "gemm_nt_f32: grid too large");
-#define DIR_G(TJ)                                                                              \
-    hipLaunchKernelGGL(gemm_nt_f32_kernel<TJ>, dim3((unsigned)nblk), dim3(256), 0, stream, P,  \
-                       ldp, Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, tiles_i, vec_ok)
+    const int ksplit = gemm_splitk_factor(NP, NQ, K);
+    float* partial = nullptr;
+    bool own = false;
+    if (ksplit > 1) {
+        const size_t need = (size_t)ksplit * NQ * NP * sizeof(float);
+        if (scratch && scratch_bytes >= need) {
+            partial = scratch;
+        } else {   // callers without a workspace (the C-ABI entry points): stream-ordered scratch
+            DIR_HIP_CHECK(hipMallocAsync((void**)&partial, need, stream));
+            own = true;
+        }
+    }
+#define DIR_G(TJ)                                                                                        \
+    hipLaunchKernelGGL(gemm_nt_f32_kernel<TJ>, dim3((unsigned)nblk, (unsigned)ksplit), dim3(256), 0, stream, P, \
+                       ldp, Q, ldq, out, ldo, NP, NQ, K, qsub, bias, alpha, tiles_i, vec_ok, ksplit, partial)
     switch (tj) {
         case 1: DIR_G(1); break;
         case 2: DIR_G(2); break;
@@ -267,7 +320,18 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
         default: DIR_G(4); break;
     }
 #undef DIR_G
-    DIR_HIP_CHECK(hipGetLastError());
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && ksplit > 1) {
+        const long total = (long)NP * NQ;
+        hipLaunchKernelGGL(gemm_splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           partial, out, ldo, NP, NQ, ksplit, bias, alpha);
+        e = hipGetLastError();
+    }
+    if (own) {
+        const hipError_t fe = hipFreeAsync(partial, stream);
+        if (e == hipSuccess) e = fe;
+    }
+    DIR_HIP_CHECK(e);
     return DIR_OK;
 }
 

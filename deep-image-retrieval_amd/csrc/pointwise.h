@@ -27,9 +27,13 @@ int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const fl
                  double* ap_out, hipStream_t stream);
 int expand_descriptors(const float* descs, int n, const float* db, int m, int D, int k, float alpha,
                        int self_set, float* out, float* sim, size_t sim_bytes, hipStream_t stream);
+// scratch (optional): fp32 workspace for the split-K partial sums of shapes with few output tiles; without one
+// the partials live in stream-ordered memory (hipMallocAsync)
+constexpr size_t kGemmSplitKMaxBytes = 64u << 20;
+int gemm_splitk_factor(int NP, int NQ, int K);
 int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP,
                 int NQ, int K, const float* qsub, const float* bias, const float* alpha,
-                hipStream_t stream);
+                hipStream_t stream, float* scratch = nullptr, size_t scratch_bytes = 0);
 // large-database similarity on the bf16 matrix cores at fp32 accuracy (sim_split.hip)
 size_t similarity_split_workspace_bytes(int NQ, int K);
 bool similarity_split_admissible(const float* P, int ldp, const float* Q, int ldq, int NP, int NQ, int K);

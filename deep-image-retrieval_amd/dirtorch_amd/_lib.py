@@ -87,6 +87,7 @@ SIGNATURES = {
     'dir_upsample_add': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p]),
     'dir_l2norm_rows': (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
+    'dir_gemm_splitk_factor': (c_int, [c_int, c_int, c_int]),
     'dir_gemm_nt_f32': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'dir_fc_l2': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

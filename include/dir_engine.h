@@ -228,7 +228,12 @@ int dir_l2norm_rows(float* x, int rows, int cols, float eps, void* stream);
  *   otherwise - e.g. --whitenv 50).  Used as
  *     FC          : P = fc.weight, Q = pooled features, bias = fc.bias   (rmac_resnet.py:66)
  *     PCA whiten  : P = components_[:v], Q = X, qsub = mean_, alpha = 1/(m*var^p) (common.py:221-232)
- *     similarity  : P = database descriptors, Q = queries -> scores[Q][N]       (common.py:30-38) */
+ *     similarity  : P = database descriptors, Q = queries -> scores[Q][N]       (common.py:30-38)
+ *   Shapes with fewer than 128 output tiles (128 x 32..128) and K >= 512 - the FC of a batch, PCA whitening of a few
+ *   hundred descriptors - run as up to 16 K slices whose fp32 partial sums (stream-ordered scratch, <= 64 MB) are
+ *   added in slice order by a second kernel: same sums, another association, run-to-run identical.
+ *   dir_gemm_splitk_factor (host-only) tells how many slices a shape gets. */
+int dir_gemm_splitk_factor(int NP, int NQ, int K);
 int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo,
                     int NP, int NQ, int K, const float* qsub, const float* bias,
                     const float* alpha, void* stream);

@@ -309,9 +309,18 @@ def test_l2norm_rows_and_idempotence():
 
 
 @pytest.mark.parametrize('NP,NQ,K', [(2048, 1, 2048), (2048, 8, 2048), (96, 40, 96), (33, 7, 96),
-                                      (130, 70, 64), (257, 131, 128), (5, 200, 36)])
+                                      (130, 70, 64), (257, 131, 128), (5, 200, 36),
+                                      # few output tiles + long K: the split-K form (FC of a batch: 16 slices at 32 / 64
+                                      # rows, 8 at 256; ragged tiles; K slabs that do not divide; the gather path of K % 4 != 0)
+                                      (2048, 32, 2048), (2048, 64, 2048), (2048, 256, 2048), (515, 33, 2080),
+                                      (300, 70, 1031), (2048, 5, 512)])
 def test_gemm_nt_f32(NP, NQ, K):
     ops = _ops()
+    from dirtorch_amd import _lib
+    slices = _lib.load().dir_gemm_splitk_factor(NP, NQ, K)
+    print('\n[gemm] %dx%dx%d: K slices %d' % (NP, NQ, K, slices))
+    assert (slices > 1) == ((NP, NQ, K) in ((2048, 32, 2048), (2048, 64, 2048), (2048, 256, 2048), (515, 33, 2080),
+                                            (300, 70, 1031), (2048, 5, 512), (2048, 8, 2048)))
     P = _rand((NP, K), 16)
     Q = _rand((NQ, K), 17)
     sub = _rand((K,), 18)
