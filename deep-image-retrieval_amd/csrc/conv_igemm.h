@@ -53,6 +53,7 @@ struct ConvVariant {
                                // 3 = register-stationary weights 1x1 (conv_wreg.hip),
                                // 4 = kind 2 with the pixel operand three K-steps deep (conv_persist.hip, XDEEP),
                                // 5 = LDS-patch 3x3 for wide layers, one 64-channel plane at a time (conv_patch.hip)
+                               // 6 = LDS-patch 3x3, 512 pixels x 128 channels, double-buffered 32-channel planes (conv_patchw.hip)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
     ConvLaunchFn launch_dual[2]; // two-source K instantiation (ConvArgs::x2: conv3 + downsample in one GEMM), or nullptr
 };
@@ -65,6 +66,8 @@ bool conv_c3c1_admissible(const ConvArgs& a);
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3s_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3s_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+bool conv_patch3x3w_admissible(const ConvArgs& a);
+hipError_t conv_patch3x3w_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

@@ -502,6 +502,8 @@ static const ConvVariant kVariants[] = {
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
     // ... for the wide 3x3 layers (256 / 512 channels): the patch one 64-channel plane at a time, Cout tiled by 256
     {"256x256_patch3x3s", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 5, {nullptr, nullptr}, {nullptr, nullptr}},
+    // ... 512 pixels x 128 channels per workgroup, 32-channel planes double-buffered, one filter row per weight stage
+    {"512x128_patch3x3w", 512, 128, 512, 3, 32, {nullptr, nullptr}, {nullptr, nullptr}, 6, {nullptr, nullptr}, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}, {nullptr, nullptr}},
     // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
@@ -519,6 +521,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     const ConvVariant& cv = kVariants[v];
     if (cv.kind == 1) return a.Cout == cv.BN && conv_patch3x3_admissible(a);
     if (cv.kind == 5) return conv_patch3x3s_admissible(a);
+    if (cv.kind == 6) return conv_patch3x3w_admissible(a);
     if (cv.kind == 2) return conv1x1_persist_admissible(a);
     if (cv.kind == 4) return conv1x1_persist_admissible(a) && a.res == nullptr;   // the deep-X form has no residual path
     if (cv.kind == 3) return conv1x1_wreg_admissible(a);
@@ -559,8 +562,16 @@ int conv_pick_variant(const ConvArgs& a) {
     }
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };
-    Cand c[10];
+    Cand c[11];
     int n = 0;
+    {
+        // 3x3 stride 1 over >= 128 channels (conv2 of layer2 / 3 / 4): 512 pixels x 128 channels per workgroup with
+        // double-buffered 32-channel planes (conv_patchw.hip) - A/B at batch 32 (gpurun_out/pw): layer2 175 -> 153 us,
+        // layer3 133 -> 124 us, layer4 121 -> 113 us.  Falls through (like every candidate) when it is not admissible
+        // or leaves CUs without a tile.
+        static const bool no_pw = getenv("DIRTORCH_AMD_NO_PATCHW") != nullptr;   // A/B and bisecting
+        if (!no_pw && a.R * a.S > 1 && a.Cin >= 128) c[n++] = {"512x128_patch3x3w", 1};
+    }
     if (T <= 1 || a.Cout % 128 != 0) {
         c[n++] = {"256x64_w4x1", 1}, c[n++] = {"128x64_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
     } else if (a.Cout % 256 == 0 && T >= 6) {
@@ -721,6 +732,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     }
     hipError_t e = cv.kind == 1   ? conv_patch3x3_launch(a, dtype, stream)
                    : cv.kind == 5 ? conv_patch3x3s_launch(a, dtype, stream)
+                   : cv.kind == 6 ? conv_patch3x3w_launch(a, dtype, stream)
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
                    : cv.kind == 4 ? conv1x1_persist_launch(a, dtype, stream, true)
                    : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)

@@ -42,6 +42,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
     bn = int(name.split('_')[0].split('x')[1])
     if 'wreg1x1' in name:
         return k == 1 and stride == 1 and pad == 0 and Cout % 512 == 0 and Cin in (128, 256) and has_res
+    if 'patch3x3w' in name:              # 512 pixels x 128 channels per workgroup, 32-channel planes
+        return k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0 and Cin >= 64 and Cout % 128 == 0
     if 'patch3x3s' in name:              # wide layers, one 64-channel plane at a time, Cout tiled by 256
         return k == 3 and stride == 1 and pad == 1 and Cin in (256, 512) and Cout % 256 == 0
     if 'patch3x3' in name:
@@ -100,6 +102,7 @@ CONV_SHAPES = [
     ('3x3_patch128_exact', 1, 16, 64, 128, 128, 3, 1, 1, False, False),
     ('3x3_wide256_ragged', 2, 13, 37, 256, 256, 3, 1, 1, False, True),    # 2 x 2 spatial tiles per image, ragged both ways
     ('3x3_wide512_res', 1, 9, 33, 512, 512, 3, 1, 1, True, False),        # two Cout tiles sharing a patch
+    ('3x3_tall_37x33', 1, 37, 33, 128, 256, 3, 1, 1, True, True),        # three 16-row tiles (16, 16, 5) x two 32-column tiles (32, 1)
     ('1x1_wreg_k256', 2, 17, 13, 256, 1024, 1, 1, 0, True, True),       # 442 pixels: ragged last tile of 64
     ('1x1_wreg_k128_norelu', 3, 20, 20, 128, 512, 1, 1, 0, True, False),
 ]
