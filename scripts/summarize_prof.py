@@ -47,6 +47,9 @@ def short(name):
     m = re.search(r'conv_patch3x3s_kernel<dir::(\w+), (\d+)>', name)
     if m:
         return 'conv_igemm<256x256_patch3x3s>[%s]' % m.group(1).lower()
+    m = re.search(r'conv_patch3x3w_kernel<dir::(\w+)>', name)
+    if m:
+        return 'conv_igemm<512x128_patch3x3w>[%s]' % m.group(1).lower()
     m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)', name)
     if m:
         return 'conv_igemm<256x%s_patch3x3>[%s]' % (m.group(2), m.group(1).lower())
@@ -117,13 +120,15 @@ def pmc(fd, wd, out, traffic=None):
 # ---- per-kernel roofline table ---------------------------------------------------------------------
 ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
 PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
+FOLLOW_UP = ('gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel')
 MEASURED_TF, MEASURED_GBS = 1582.0, 6305.0   # scripts/probes/*_ceiling.hip on a pool box (profiles/r02_*_ceiling.txt)
 
 
 def bench_kernel_name(k):
     """rocprof short name -> the name bench.py's profile records carry."""
     k = re.sub(r'(/stem)?\[\w+\]$', '', k)
-    return {'stem_pool_kernel': 'stem_pool', 'prep_input_kernel': 'prep_input', 'global_pool_kernel': 'global_pool',
+    return {'stem_pool_kernel': 'stem_pool', 'stem_pool_persist_kernel': 'stem_pool', 'prep_input_kernel': 'prep_input',
+            'global_pool_kernel': 'global_pool',
             'gemm_nt_small_kernel': 'gemm_nt_f32', 'gemm_nt_f32_kernel': 'gemm_nt_f32',
             'maxpool_kernel': 'maxpool_3x3s2', 'upsample_add_kernel': 'upsample_add'}.get(k, k)
 
@@ -151,6 +156,10 @@ def aligned(d, seq, counters=None):
     L = len(seq)
     for disp, k, dur in rows:
         want = seq[pos % L]['kernel']
+        if k in FOLLOW_UP and out:     # second kernel of a launch record (split-K finalize): its time joins the record
+            i, d0, v0 = out[-1]
+            out[-1] = (i, d0 + dur, v0)
+            continue
         if k != want:
             # tolerate kernels outside the recorded sequence (e.g. a warm-up autotune); resync on the head
             if k == seq[0]['kernel']:
