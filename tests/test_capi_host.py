@@ -137,3 +137,19 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_w4x2_s3', 1)
     assert pick(32, 64, 256, 1024, 1, 1, 0)[0] != '64x512_wreg1x1'
     assert pick(2, 64, 256, 1024, 1, 1, 1)[0] != '64x512_wreg1x1'
+
+
+def test_gemm_splitk_choices():
+    """How many K slices the fp32 GEMM runs a shape with (host-only logic, dir_gemm_splitk_factor): the FC of a batch and
+    PCA whitening / similarity of small sets split, anything with >= 128 output tiles or a short K does not, and a
+    handful of Q rows stays on the one-wave-per-two-rows kernel."""
+    from dirtorch_amd import _lib
+    f = _lib.load().dir_gemm_splitk_factor
+    assert f(2048, 32, 2048) == 16 and f(2048, 64, 2048) == 16 and f(2048, 256, 2048) == 8    # FC, batch 32 / 64 / 256
+    assert f(4993, 70, 2048) == 6                                  # ROxford-size similarity: 40 tiles
+    assert f(2048, 1, 2048) == 1 and f(2048, 4, 2048) == 1         # batch 1-4: the row-per-wave kernel
+    assert f(1006322, 70, 2048) == 1 and f(2048, 100000, 2048) == 1   # plenty of tiles
+    assert f(2048, 32, 256) == 1                                   # 8 slabs of K: not worth a second kernel
+    for NP, NQ, K in ((2048, 512, 4096), (300, 70, 1031), (515, 33, 2080)):
+        s = f(NP, NQ, K)
+        assert 1 <= s <= 16 and s * NQ * NP * 4 <= 64 << 20 and (s == 1 or (K + 31) // 32 // s >= 4)
