@@ -533,12 +533,14 @@ int dir_similarity(const float* queries, int Q, const float* database, int N, in
     if (!exact && N >= kSimSplitMinRows && similarity_split_admissible(database, D, queries, D, N, Q, D)) {
         const size_t bytes = similarity_split_workspace_bytes(Q, D);
         void* ws = nullptr;
-        DIR_HIP_CHECK(hipMallocAsync(&ws, bytes, (hipStream_t)stream));   // stream-ordered: freed after the kernels
-        const int rc = similarity_split(database, D, queries, D, scores, N, N, Q, D, ws, bytes, (hipStream_t)stream);
-        const hipError_t fe = hipFreeAsync(ws, (hipStream_t)stream);
-        if (rc != DIR_OK) return rc;
-        DIR_HIP_CHECK(fe);
-        return DIR_OK;
+        if (hipMallocAsync(&ws, bytes, (hipStream_t)stream) == hipSuccess) {   // stream-ordered: freed after the kernels
+            const int rc = similarity_split(database, D, queries, D, scores, N, N, Q, D, ws, bytes, (hipStream_t)stream);
+            const hipError_t fe = hipFreeAsync(ws, (hipStream_t)stream);
+            if (rc != DIR_OK) return rc;
+            DIR_HIP_CHECK(fe);
+            return DIR_OK;
+        }
+        (void)hipGetLastError();   // no memory pool / out of memory: the exact chain below needs no scratch
     }
     return gemm_nt_f32(database, D, queries, D, scores, N, N, Q, D, nullptr, nullptr, nullptr,
                        (hipStream_t)stream);

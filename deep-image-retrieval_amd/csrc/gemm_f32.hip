@@ -298,16 +298,19 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
     const int tiles_j = ceil_div(NQ, 32 * tj);
     const long nblk = (long)tiles_i * tiles_j;
     if (nblk >= (1L << 31)) return fail(DIR_ERR_INVALID, "gemm_nt_f32: grid too large");
-    const int ksplit = gemm_splitk_factor(NP, NQ, K);
+    int ksplit = gemm_splitk_factor(NP, NQ, K);
     float* partial = nullptr;
     bool own = false;
     if (ksplit > 1) {
         const size_t need = (size_t)ksplit * NQ * NP * sizeof(float);
         if (scratch && scratch_bytes >= need) {
             partial = scratch;
-        } else {   // callers without a workspace (the C-ABI entry points): stream-ordered scratch
-            DIR_HIP_CHECK(hipMallocAsync((void**)&partial, need, stream));
-            own = true;
+        } else if (hipMallocAsync((void**)&partial, need, stream) == hipSuccess) {
+            own = true;   // callers without a workspace (the C-ABI entry points): stream-ordered scratch
+        } else {          // no memory pool on this device / out of memory: the unsplit form is always available
+            (void)hipGetLastError();
+            partial = nullptr;
+            ksplit = 1;
         }
     }
 #define DIR_G(TJ)                                                                                        \
