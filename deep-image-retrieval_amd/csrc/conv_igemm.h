@@ -36,6 +36,7 @@ struct ConvArgs {
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)
+    int no_xcd_map;                          // persistent kernels: 1 = tiles follow blockIdx (A/B; default 0 = XCD-aware)
     int flat;                                // 1x1, stride 1, no padding: pixel m reads pixel m
     uint32_t div_ohw_mul, div_ohw_shr;       // exact n / (OH*OW) and n / OW for n < 2^31
     uint32_t div_ow_mul, div_ow_shr;

@@ -113,7 +113,11 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
     const int xfrag = (wm * TM * 32) * 128;
     const int wfrag = (XDEEP ? 0 : XS) + (wn * TN * 32) * 128;
 
-    int tile = blockIdx.x;
+    // Hardware places workgroup b on XCD b % 8.  With tile = b the tiles_n channel tiles of one pixel tile would sit
+    // on tiles_n DIFFERENT XCDs, each fetching the same pixels from HBM into its own L2 (layer4's 512 -> 2048 conv3:
+    // PMC traffic 1.8x the algorithmic bytes).  The bijective remap gives every XCD a contiguous run of tiles, so the
+    // channel tiles of a pixel tile share one L2; tile + gridDim.x keeps that property round after round.
+    int tile = a.no_xcd_map ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= ntiles) return;
     // The bias of a tile (its accumulators start there) is fetched BEFORE that tile's first DMA goes
     // out: the compiler waits for ordinary loads in program order, so a bias load issued after the
@@ -324,6 +328,7 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
+    b.no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting
     // exact n / d for n < 2^31 (same constants as conv_igemm.hip)
     auto fd = [](uint32_t d, uint32_t& mul, uint32_t& shr) {
         if (d <= 1) { mul = 0; shr = 0; return; }

@@ -57,8 +57,12 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     const int nsl = a.Cout / 512;
     const int mt = (a.M + BM - 1) / BM;
     const int per = gridDim.x / nsl;           // workgroups per channel slice (launcher: G % nsl == 0)
-    const int sl = blockIdx.x % nsl;
-    int tile = blockIdx.x / nsl;
+    // the nsl channel slices of a pixel tile on the SAME XCD (consecutive ids of the remapped order), so that the
+    // pixel operand comes from HBM once per tile instead of once per slice (layer3: PMC traffic 1.13x -> the 67 MB
+    // of conv2's output were fetched by two L2s)
+    const int lid = a.no_xcd_map ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    const int sl = lid % nsl;
+    int tile = lid / nsl;
     if (tile >= mt) return;
     const int n_wave = sl * 512 + wave * BNW;  // first output channel of this wave
 
@@ -243,6 +247,7 @@ static hipError_t launch_wreg(const ConvArgs& a, hipStream_t stream) {
     const int mt = (a.M + 63) / 64;
     int per = 256 / nsl;                       // one persistent workgroup per CU
     if (per > mt) per = mt;
+    b.no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting
     hipLaunchKernelGGL(kern, dim3(per * nsl), dim3(512), LDS, stream, b);
     return hipGetLastError();
 }
