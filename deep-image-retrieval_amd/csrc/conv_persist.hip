@@ -328,7 +328,8 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
-    b.no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting
+    static const bool no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting (read once)
+    b.no_xcd_map = no_xcd_map;
     // exact n / d for n < 2^31 (same constants as conv_igemm.hip)
     auto fd = [](uint32_t d, uint32_t& mul, uint32_t& shr) {
         if (d <= 1) { mul = 0; shr = 0; return; }
