@@ -29,6 +29,17 @@ def make_net(arch, sd, dtype):
     return net.eval()
 
 
+_CACHE = {}
+
+
+def cached(key, make):
+    """The CPU oracle is most of this file's wall time and the fp32 reference of a case does not depend on the
+    engine's dtype: compute it once per (case) and share it between the bf16 and fp16 runs."""
+    if key not in _CACHE:
+        _CACHE[key] = make()
+    return _CACHE[key]
+
+
 def oracle_desc(sd, arch, x, quant=None, chunk=8):
     import dir_oracle as O
     rows = [O.rmac_forward(sd, arch, x[i:i + chunk], quant=quant).reshape(-1, sd['fc.weight'].shape[0])
@@ -55,7 +66,7 @@ def test_descriptor_vs_oracle_at_baseline_sizes(tag, arch, B, H, W, dtype):
     net = make_net(arch, sd, dtype)
     with torch.no_grad():
         got = net(x.cuda()).cpu().numpy().reshape(B, -1)
-    ref = oracle_desc(sd, arch, x)
+    ref = cached(('desc', tag), lambda: oracle_desc(sd, arch, x))
     assert np.isfinite(got).all()
     err = 1 - O.cosine(got, ref)
     print('\n[scale] %s %s: 1-cos vs fp32 oracle max %.3e mean %.3e' % (tag, dtype, err.max(), err.mean()))
@@ -72,12 +83,12 @@ def test_calibrated_checkpoint_error_vs_ideal_16bit(arch, B, H, W, CB, dtype):
     and no more: engine error <= 3 x emulation error, and the engine sits as close to the emulation as
     the emulation sits to fp32."""
     import dir_oracle as O
-    sd = O.calibrated_state_dict(arch, O.synth_images(99, CB, H, W), seed=7)
+    sd = cached(('calib-sd', arch, H, W), lambda: O.calibrated_state_dict(arch, O.synth_images(99, CB, H, W), seed=7))
     x = O.synth_images(4, B, H, W)
     net = make_net(arch, sd, dtype)
     with torch.no_grad():
         got = net(x.cuda()).cpu().numpy().reshape(B, -1)
-    ref = oracle_desc(sd, arch, x)
+    ref = cached(('calib-ref', arch, H, W), lambda: oracle_desc(sd, arch, x))
     emu = oracle_desc(sd, arch, x, quant=dtype)
     e_got = 1 - O.cosine(got, ref)
     e_emu = 1 - O.cosine(emu, ref)
