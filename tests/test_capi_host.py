@@ -153,3 +153,35 @@ def test_gemm_splitk_choices():
     for NP, NQ, K in ((2048, 512, 4096), (300, 70, 1031), (515, 33, 2080)):
         s = f(NP, NQ, K)
         assert 1 <= s <= 16 and s * NQ * NP * 4 <= 64 << 20 and (s == 1 or (K + 31) // 32 // s >= 4)
+
+
+def test_profile_tooling_knows_every_engine_kernel():
+    """scripts/summarize_prof.py aligns rocprofv3 dispatches with bench.py's launch records BY NAME; a kernel it cannot
+    name silently drops out of the per-kernel roofline table (this happened to two new kernels in round 2).  Take the
+    kernel names from the library itself (host-side launch stubs) and require: every convolution kernel maps onto a
+    registered tile-variant name or a fused-seam name, every other kernel of the forward path onto the name bench.py's
+    profile records carry."""
+    import re
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import summarize_prof as S
+    from dirtorch_amd import _lib, ops
+    so = os.path.join(ROOT, 'deep-image-retrieval_amd', 'dirtorch_amd', 'libdir_engine.so')
+    _lib.load()
+    raw = subprocess.run('strings -n 8 %s | grep -E "^_Z.*__device_stub__" | sort -u | c++filt' % so, shell=True,
+                         capture_output=True, text=True, check=True).stdout.splitlines()
+    names = sorted({re.sub(r'\(.*$', '', l).replace('__device_stub__', '').replace('void ', '') for l in raw})
+    assert len(names) > 100, names[:5]
+    variants = set(ops.conv_variant_names())
+    forward = {'stem_pool', 'prep_input', 'global_pool', 'gemm_nt_f32', 'maxpool_3x3s2', 'upsample_add'}
+    other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_counts_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
+             'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'split_queries_kernel', 'fill_noise_kernel',
+             'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel'}
+    for n in names:
+        k = S.bench_kernel_name(S.short(n))
+        if 'conv' in n and 'finalize' not in n and 'naive' not in n:
+            m = re.match(r'^conv_igemm<([^>/]+)(/splitk|/dual)?>$', k)
+            assert (m and m.group(1) in variants) or re.match(r'^conv_c3c1<(64|128)(,ds)?>$', k), (n, k)
+        else:
+            assert k in forward or k in other, (n, k)
