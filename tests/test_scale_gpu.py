@@ -134,3 +134,71 @@ def test_trunk_tiles_at_headline_size(dtype):
     # made of garbage has rel L2 ~ 1
     assert tile_rel.max() < 1.5 * np.median(tile_rel), (tile_rel.max(), np.median(tile_rel))
     assert tile_max.max() < 0.05 * scale, (tile_max.max(), scale)
+
+
+# ---- the configuration bench.py times: kernel mix asserted, rows and tiles against the CPU oracle ------------
+# dir_conv_heuristic (engine.hip run_conv) picks DIFFERENT kernels at batch 32 than at batch 2: the 512x128
+# LDS-patch 3x3 (conv2 of layers 2-4, the dominant kernel of the bench), the register-stationary conv3, the
+# persistent 256x256 conv1 / conv3 (+ its three-deep form for layer4's conv1), the fused layer2 seam and the
+# two-source GEMMs.  Descriptors do not depend on the batch an image travels in, so three rows of the batch
+# (first, middle, last: the first / an interior / the last tile of every persistent workgroup's walk) are
+# enough, and the CPU oracle only has to run three images.
+TIMED_MIX = {
+    32: {'layer2.1.conv2': '512x128_patch3x3w', 'layer3.7.conv2': '512x128_patch3x3w', 'layer4.1.conv2': '512x128_patch3x3w',
+         'layer2.3.conv3': '64x512_wreg1x1', 'layer3.9.conv3': '64x512_wreg1x1',
+         'layer3.5.conv1': '256x256_persist1x1', 'layer4.2.conv3': '256x256_persist1x1',
+         'layer4.1.conv1': '256x256_persist1x1_x3'},
+    16: {'layer2.1.conv2': '512x128_patch3x3w', 'layer3.7.conv2': '512x128_patch3x3w',
+         'layer2.3.conv3': '64x512_wreg1x1', 'layer3.9.conv3': '64x512_wreg1x1',
+         'layer3.5.conv1': '256x256_persist1x1'},
+}
+ROWS = {32: (0, 13, 31), 16: (0, 6, 15)}
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B', [32, 16])
+def test_timed_configuration_vs_oracle(B, dtype):
+    """ResNet-101 @ 1024^2 at the batch bench.py runs (32; 16 has another layer4 mix): (1) the profile shows
+    the kernels the bench number is made of, (2) descriptors of rows {first, middle, last} agree with the fp32
+    oracle to the north-star 1e-4 cosine, (3) their trunk maps agree with the storage-emulating oracle per
+    64-pixel tile (reference: dirtorch/nets/rmac_resnet.py:39-69, backbones/resnet.py:67-87,157-174)."""
+    import dir_oracle as O
+    arch, S = 'resnet101', 1024
+    rows = list(ROWS[B])
+    sd = O.synth_state_dict(arch, seed=7)
+    x = cached(('timed-x', B), lambda: O.synth_images(4, B, S, S))
+    net = make_net(arch, sd, dtype)
+    xg = x.cuda()
+    net.set_profiling(True)
+    with torch.no_grad():
+        got = net(xg).cpu().numpy()
+    used = {r['name']: r['kernel'] for r in net.get_profile()}
+    net.set_profiling(False)
+    for layer, variant in TIMED_MIX[B].items():
+        assert used.get(layer) == 'conv_igemm<%s>' % variant, (layer, used.get(layer))
+    assert used.get('layer2.1.c3c1') == 'conv_c3c1<128>' and used.get('layer1.0.ds+c3c1') == 'conv_c3c1<64,ds>', used
+    for s in (2, 3, 4):
+        assert used.get('layer%d.0.ds+conv3' % s, '').endswith('/dual>'), used
+    assert np.isfinite(got).all()
+    ref = cached(('timed-desc', B), lambda: oracle_desc(sd, arch, x[rows], chunk=1))
+    err = 1 - O.cosine(got[rows], ref)
+    print('\n[timed] B=%d %s: 1-cos vs fp32 oracle rows %s: %s' % (B, dtype, rows, err))
+    assert np.all(err < 1e-4), err
+    # batch independence of the rows NOT sent to the oracle: every row of the batch equals the row computed
+    # in the oracle-checked batch-2 configuration to 16-bit-rounding noise (other kernels, same arithmetic)
+    with torch.no_grad():
+        small = torch.cat([net(xg[i:i + 2]).reshape(2, -1) for i in range(0, B, 2)]).cpu().numpy()
+    assert np.all(1 - O.cosine(got, small) < 2e-5), (1 - O.cosine(got, small)).max()
+    if B != 32:
+        return
+    # trunk maps of the three rows, per 64-pixel tile (the bench batch only: the CPU side costs ~5 s per image)
+    feat = net.forward_features(xg)[rows].float().cpu()              # [3, 32, 32, 2048]
+    with torch.no_grad():
+        fref = torch.cat([O.resnet_features(sd, arch, x[i:i + 1], quant=dtype) for i in rows]).permute(0, 2, 3, 1).contiguous()
+    g = feat.reshape(-1, 64, feat.shape[-1])
+    r = fref.reshape(-1, 64, feat.shape[-1])
+    tile_rel = ((g - r).flatten(1).norm(dim=1) / r.flatten(1).norm(dim=1)).numpy()
+    whole = float((feat - fref).norm() / fref.norm())
+    print('[timed] B=%d %s: trunk whole-map rel L2 %.3e, per-tile max %.3e median %.3e' % (B, dtype, whole, tile_rel.max(), np.median(tile_rel)))
+    assert whole < (1.2e-2 if dtype == 'bf16' else 1.5e-3), whole
+    assert tile_rel.max() < 1.5 * np.median(tile_rel), (tile_rel.max(), np.median(tile_rel))
