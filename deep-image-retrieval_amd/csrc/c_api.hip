@@ -128,6 +128,13 @@ int dir_forward(dir_engine* e, const void* img, int B, int H, int W, int fmt, fl
     DIR_CATCH
 }
 
+int dir_engine_overflow(dir_engine* e, void* stream, int* overflowed) {
+    DIR_TRY
+    if (!e || !overflowed) return fail(DIR_ERR_INVALID, "overflow: null argument");
+    return e->overflow((hipStream_t)stream, overflowed);
+    DIR_CATCH
+}
+
 int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, int fmt,
                          void* feat_out, int* h, int* w, int* c, void* ws, size_t ws_bytes,
                          void* stream) {

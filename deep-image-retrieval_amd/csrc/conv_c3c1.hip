@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     const int per = gridDim.x;
     int tile = blockIdx.x;
     if (tile >= mt) return;
+    Ovf<DT> ovf;
     const int n_wave = wave * CW;               // phase A: first output channel of this wave
 
     // ---- weights -> registers, once --------------------------------------------------------------
@@ -225,6 +226,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row_off(m0 + j * 32 + mrow), i * 64, 0);
+                    ovf.see(ov);
                     // the same 16 bytes into the out-tile (B operand of phase B)
                     const int n = n_wave + i * 32 + ecol, p = j * 32 + mrow;
                     *(u32x4_t*)(otile + (n >> 6) * (BM * 128) + p * 128 + ((((n & 63) >> 3) ^ ((p >> 1) & 7)) << 4)) = ov;
@@ -312,6 +314,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
                     const int m = m0 + j * 32 + mrow;
                     const uint32_t off = m < a.M ? (uint32_t)m * (uint32_t)(P2 * 2) + (uint32_t)((nt * 32 + ecol) * 2) : kOOBf;
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y2, off, 0, 0);
+                    ovf.see(ov);
                 }
             }
         }
@@ -321,6 +324,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
         cur ^= 1;
         __syncthreads();   // (4) next t2 tile staged; out-tile and staging areas free again
     }
+    ovf.flush(a.ovf);
 }
 
 bool conv_c3c1_admissible(const ConvArgs& a) {

@@ -33,6 +33,7 @@ struct ConvArgs {
     // pixel (b, oh, ow) reads x2 pixel (b, oh*stride2, ow*stride2)
     int H2, W2, stride2;
     uint32_t x2_bytes;
+    int* ovf;              // fp16 overflow word (dir_common.h Ovf), or nullptr
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)

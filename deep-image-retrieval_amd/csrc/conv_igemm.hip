@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         if (++slot_c == NST) slot_c = 0;
     }
     __syncthreads();  // all fragment reads done before the epilogue reuses the ring
+    Ovf<DT> ovf;
 
     // ---- epilogue: acc -> LDS (fp32, pixel-major) -> residual / ReLU / convert -> 16-byte stores --
     char* ebase = smem + wave * (32 * EROW);
@@ -386,12 +387,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                 gstore16(a.y + o, ov);
+                ovf.see(ov);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    ovf.flush(a.ovf);
 }
 
 // ---- variant table ----------------------------------------------------------------------------
@@ -637,7 +640,7 @@ int conv_pick_dual_variant(const ConvArgs& a) {
 template <class DT>
 __global__ void conv_splitk_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                             const uint16_t* __restrict__ res, uint16_t* __restrict__ y,
-                                            long total8, int Cout, long MC, int ksplit, int relu) {
+                                            long total8, int Cout, long MC, int ksplit, int relu, int* ovf_flag) {
     const long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i8 >= total8) return;
     const long o = i8 * 8;
@@ -670,6 +673,9 @@ __global__ void conv_splitk_finalize_kernel(const float* __restrict__ partial, c
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
     gstore16(y + o, ov);
+    Ovf<DT> ovf;
+    ovf.see(ov);
+    ovf.flush(ovf_flag);
 }
 
 size_t conv_splitk_bytes(const ConvArgs& a, int ksplit) {
@@ -745,10 +751,10 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
         const dim3 grid((unsigned)((total8 + 255) / 256));
         if (dtype == DIR_BF16)
             hipLaunchKernelGGL(conv_splitk_finalize_kernel<BF16>, grid, dim3(256), 0, stream, a.partial, a.bias,
-                               a.res, a.y, total8, a.Cout, MC, a.ksplit, a.relu);
+                               a.res, a.y, total8, a.Cout, MC, a.ksplit, a.relu, a.ovf);
         else
             hipLaunchKernelGGL(conv_splitk_finalize_kernel<FP16>, grid, dim3(256), 0, stream, a.partial, a.bias,
-                               a.res, a.y, total8, a.Cout, MC, a.ksplit, a.relu);
+                               a.res, a.y, total8, a.Cout, MC, a.ksplit, a.relu, a.ovf);
         e = hipGetLastError();
         if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv split-K finalize: ") + hipGetErrorString(e));
     }

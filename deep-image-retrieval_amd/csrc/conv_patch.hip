@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(NTH) conv_patch3x3_kernel(const ConvArgs a) {
         }
     }
     __syncthreads();  // every wave is done with the patch before it becomes epilogue staging
+    Ovf<DT> ovf;
 
     // ---- epilogue (as conv_igemm): acc -> LDS fp32 -> ReLU -> 16-byte stores ------------------------
     char* ebase = smem + wave * (32 * EROW);
@@ -219,12 +220,14 @@ __global__ void __launch_bounds__(NTH) conv_patch3x3_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                 gstore16(a.y + o, ov);
+                ovf.see(ov);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    ovf.flush(a.ovf);
 }
 
 bool conv_patch3x3_admissible(const ConvArgs& a) {
@@ -415,6 +418,7 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
         }
     }
     __syncthreads();  // plane and weight slots become epilogue staging
+    Ovf<DT> ovf;
 
     char* ebase = smem + wave * (32 * EROW);
     constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
@@ -461,12 +465,14 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                 gstore16(a.y + o, ov);
+                ovf.see(ov);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    ovf.flush(a.ovf);
 }
 
 bool conv_patch3x3s_admissible(const ConvArgs& a) {

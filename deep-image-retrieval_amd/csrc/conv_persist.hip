@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
     // channel tiles of a pixel tile share one L2; tile + gridDim.x keeps that property round after round.
     int tile = a.no_xcd_map ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= ntiles) return;
+    Ovf<DT> ovf;
     // The bias of a tile (its accumulators start there) is fetched BEFORE that tile's first DMA goes
     // out: the compiler waits for ordinary loads in program order, so a bias load issued after the
     // prefetches would drag a wait for all of them to the top of every tile.
@@ -290,6 +291,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                         gstore16(a.y + ((size_t)m * a.Cout + n_wave + h * 64 + ecol), ov);
+                        ovf.see(ov);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -306,6 +308,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         }
         tile = next;
     }
+    ovf.flush(a.ovf);
 }
 
 bool conv1x1_persist_admissible(const ConvArgs& a) {

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     const int sl = lid % nsl;
     int tile = lid / nsl;
     if (tile >= mt) return;
+    Ovf<DT> ovf;
     const int n_wave = sl * 512 + wave * BNW;  // first output channel of this wave
 
     // ---- weights -> registers, once: A-fragment of channel tile i, k-slice ks ------------------
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = DT::pack(v[2 * e], v[2 * e + 1]);
                     __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, row_off(m), 0, 0);
+                    ovf.see(ov);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -224,6 +226,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
         cur ^= 1;
         __builtin_amdgcn_s_barrier();
     }
+    ovf.flush(a.ovf);
 }
 
 bool conv1x1_wreg_admissible(const ConvArgs& a) {

@@ -117,6 +117,41 @@ __device__ inline void gstore16(void* p, u32x4_t v) {
     *(DIR_GLOBAL u32x4_t*)p = v;
 }
 
+// ---- fp16 overflow tripwire -----------------------------------------------------------------------
+// The reference computes in fp32 and cannot overflow (dirtorch/nets/backbones/resnet.py:67-87); fp16 storage
+// saturates at 65504.  Overflow can only happen where an fp32 value is packed for a store, and every packed
+// value is stored, so watching the stores is a complete detector - a later ReLU (a hardware max, which drops a
+// NaN operand) or a fused consumer cannot hide the event.  Each lane keeps the packed unsigned max of the
+// |bit patterns| it stored (v_and + v_pk_max_u16 per two values); exponent all ones (inf / NaN) <=> pattern
+// >= 0x7c00.  One atomicOr per offending lane at kernel end; the engine reads the word on request
+// (dir_engine_overflow).  bf16 shares fp32's range: the tracker compiles to nothing.
+typedef __attribute__((ext_vector_type(2))) uint16_t u16x2_t;
+template <class DT>
+struct Ovf {
+    uint32_t m = 0;
+    __device__ inline void see(uint32_t w) {
+        if constexpr (DT::kDtype == DIR_FP16) {
+            // (inline asm: as plain C the max chain is re-associated across the unrolled epilogue and the packed
+            // words of several passes stay live - +18 VGPRs and a spill in the register-stationary kernels)
+            uint32_t t;
+            asm("v_and_b32 %1, 0x7fff7fff, %2\n\tv_pk_max_u16 %0, %0, %1" : "+v"(m), "=&v"(t) : "v"(w));
+        }
+    }
+    __device__ inline void see(const u32x4_t& v) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) see(v[e]);
+    }
+    __device__ inline void see(const u32x2_t& v) {
+        see(v[0]);
+        see(v[1]);
+    }
+    __device__ inline void flush(int* flag) const {
+        if constexpr (DT::kDtype == DIR_FP16) {
+            if (flag && ((m + 0x04000400u) & 0x80008000u)) atomicOr(flag, 1);
+        }
+    }
+};
+
 // Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; give each
 // XCD a contiguous run of logical tiles so neighbouring tiles (which share an operand panel) hit
 // the same 4 MiB L2.  Placement only affects speed, never results.

@@ -67,6 +67,9 @@ struct dir_engine {
     float gem_p4 = 3.f;  // adpoolc4.p
     float* d_fc_w = nullptr;
     float* d_fc_b = nullptr;
+    // fp16 overflow word (dir_common.h Ovf): every kernel that packs fp32 sums for a store ORs into it; sticky
+    // until dir_engine_overflow() reads and clears it
+    int* d_ovf = nullptr;
     // profiling
     bool profiling = false;
     bool prof_paused = false;
@@ -99,5 +102,6 @@ struct dir_engine {
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
                    hipStream_t stream);
     int prof_end(hipStream_t stream);
+    int overflow(hipStream_t stream, int* overflowed);
     void release();
 };

@@ -246,6 +246,8 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMalloc((void**)&d_fc_b, fb->data.size() * 4));
         DIR_HIP_CHECK(hipMemcpy(d_fc_b, fb->data.data(), fb->data.size() * 4, hipMemcpyHostToDevice));
     }
+    DIR_HIP_CHECK(hipMalloc((void**)&d_ovf, 256));
+    DIR_HIP_CHECK(hipMemset(d_ovf, 0, 256));
     DIR_HIP_CHECK(hipDeviceSynchronize());
     finalized = true;
     return DIR_OK;
@@ -263,7 +265,21 @@ void dir_engine::release() {
     if (d_fc_w) (void)hipFree(d_fc_w);
     if (d_fc_b) (void)hipFree(d_fc_b);
     d_fc_w = d_fc_b = nullptr;
+    if (d_ovf) (void)hipFree(d_ovf);
+    d_ovf = nullptr;
     finalized = false;
+}
+
+// ---- fp16 overflow word ------------------------------------------------------------------------------
+// Reads (and clears) the word the kernels OR into whenever they store an fp16 inf / NaN.  Synchronises `stream`.
+int dir_engine::overflow(hipStream_t stream, int* overflowed) {
+    if (!finalized) return fail(DIR_ERR_STATE, "overflow query before finalize");
+    int host = 0;
+    DIR_HIP_CHECK(hipMemcpyAsync(&host, d_ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DIR_HIP_CHECK(hipMemsetAsync(d_ovf, 0, sizeof(int), stream));
+    DIR_HIP_CHECK(hipStreamSynchronize(stream));
+    *overflowed = host != 0;
+    return DIR_OK;
 }
 
 // ---- workspace plan ---------------------------------------------------------------------------
@@ -377,6 +393,7 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
         a.pad = L.pad;
     }
     a.relu = L.relu ? 1 : 0;
+    a.ovf = d_ovf;
     a.partial = splitk_scratch;
     a.M = B * OH * OW;
     a.Ktot = a.R * a.S * a.Cin;
@@ -485,6 +502,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.y2 = t1;
     a.Cout2 = c1.Cout;
     a.relu2 = c1.relu ? 1 : 0;
+    a.ovf = d_ovf;
     if (c1.R != 1 || c1.S != 1 || c1.stride != 1 || c1.pad != 0 || c1.Cin != c3.Cout || !conv_c3c1_admissible(a))
         return DIR_OK;
     if (!sw.c3c1_force && (a.M + 63) / 64 < kSeamMinTiles) return DIR_OK;
@@ -524,6 +542,7 @@ int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t
     a.R = a.S = 1;
     a.stride = 1;
     a.relu = c3.relu ? 1 : 0;
+    a.ovf = d_ovf;
     a.M = B * OH * OW;
     a.x2 = xin;
     a.Cin2 = ds.Cin;
@@ -617,7 +636,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
                         stream);
         if (rc != DIR_OK) return rc;
         rc = stem_pool_launch(s2d, convs[0].d_w, convs[0].d_bias, cur, B, p.H2, p.W2, p.OH1, p.OW1,
-                              dtype, stream);
+                              dtype, stream, d_ovf);
         if (rc != DIR_OK) return rc;
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
     }
@@ -719,7 +738,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             rc = prof_begin("x4+up(c5)", "upsample_add", 0,
                             2.0 * ((double)B * h4 * w4 * x4_dim * 2 + (double)B * h * w * x4_dim), stream);
             if (rc != DIR_OK) return rc;
-            rc = upsample_add(x4, t1, sum, B, h4, w4, h, w, x4_dim, dtype, stream);
+            rc = upsample_add(x4, t1, sum, B, h4, w4, h, w, x4_dim, dtype, stream, d_ovf);
             if (rc != DIR_OK) return rc;
             if ((rc = prof_end(stream)) != DIR_OK) return rc;
             rc = run_conv(convs[conv3c4], sum, nullptr, t2, B, h4, w4, h4, w4, stream);

@@ -11,7 +11,7 @@ int maxpool_3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype,
 int global_pool(const void* x, float* out, int ldo, int B, int H, int W, int C, int pooling, float p,
                 float eps, float center_bias, int dtype, hipStream_t stream);
 int upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
-                 int dtype, hipStream_t stream);
+                 int dtype, hipStream_t stream, int* ovf = nullptr);
 int l2norm_rows(float* x, int rows, int cols, float eps, hipStream_t stream);
 size_t resize_workspace_bytes(int B, int H, int W, int OH, int OW);
 int resize_bilinear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, int OH, int OW, void* ws,
@@ -19,7 +19,7 @@ int resize_bilinear_u8(const uint8_t* src, uint8_t* dst, int B, int H, int W, in
 int multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,
                     hipStream_t stream);
 int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
-                     int OH, int OW, int dtype, hipStream_t stream);
+                     int OH, int OW, int dtype, hipStream_t stream, int* ovf = nullptr);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
 int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* pscores, const int* pos_off,

@@ -266,7 +266,7 @@ int global_pool(const void* x, float* out, int ldo, int B, int H, int W, int C, 
 template <class DT>
 __global__ void upsample_add_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ low,
                                     uint16_t* __restrict__ y, long total, int H, int W, int h, int w,
-                                    int C8, float sy, float sx) {
+                                    int C8, float sy, float sx, int* ovf_flag) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c8 = (int)(idx % C8);
@@ -287,10 +287,13 @@ __global__ void upsample_add_kernel(const uint16_t* __restrict__ x, const uint16
         o[e] = DT::pack(a0 + l0, a1 + l1);
     }
     gstore16(y + idx * 8, o);
+    Ovf<DT> ovf;
+    ovf.see(o);
+    ovf.flush(ovf_flag);
 }
 
 int upsample_add(const void* x, const void* low, void* y, int B, int H, int W, int h, int w, int C,
-                 int dtype, hipStream_t stream) {
+                 int dtype, hipStream_t stream, int* ovf) {
     if (C % 8 != 0) return fail(DIR_ERR_INVALID, "upsample_add: C must be a multiple of 8");
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "upsample_add: bad dtype");
     const long total = (long)B * H * W * (C / 8);
@@ -298,10 +301,10 @@ int upsample_add(const void* x, const void* low, void* y, int B, int H, int W, i
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     if (dtype == DIR_BF16)
         hipLaunchKernelGGL(upsample_add_kernel<BF16>, grid, dim3(256), 0, stream, (const uint16_t*)x,
-                           (const uint16_t*)low, (uint16_t*)y, total, H, W, h, w, C / 8, sy, sx);
+                           (const uint16_t*)low, (uint16_t*)y, total, H, W, h, w, C / 8, sy, sx, ovf);
     else
         hipLaunchKernelGGL(upsample_add_kernel<FP16>, grid, dim3(256), 0, stream, (const uint16_t*)x,
-                           (const uint16_t*)low, (uint16_t*)y, total, H, W, h, w, C / 8, sy, sx);
+                           (const uint16_t*)low, (uint16_t*)y, total, H, W, h, w, C / 8, sy, sx, ovf);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;
 }

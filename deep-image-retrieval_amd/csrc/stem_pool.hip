@@ -33,6 +33,7 @@ struct StemPoolArgs {
     uint16_t* y;         // pooled [B, PH, PW, 64]
     int B, H2, W2, OH, OW, PH, PW;
     uint32_t x_bytes;
+    int* ovf;            // fp16 overflow word (dir_common.h Ovf), or nullptr
 };
 
 template <class DT>
@@ -154,6 +155,7 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
     __syncthreads();
 
     // ---- 3x3 stride-2 max over the tile, 16 bytes (8 channels) per work item -------------------------
+    Ovf<DT> ovf;
     for (int it = tid; it < PTH * PTW * 8; it += 256) {
         const int c = it & 7;
         const int pp = it >> 3;
@@ -172,7 +174,9 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const StemPoolArgs a) {
                     best, *(const u16x8_t*)(smem + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4)));
             }
         gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, __builtin_bit_cast(u32x4_t, best));
+        ovf.see(__builtin_bit_cast(u32x4_t, best));
     }
+    ovf.flush(a.ovf);
 }
 
 // ---- persistent form ---------------------------------------------------------------------------------------
@@ -244,6 +248,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoo
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
+    Ovf<DT> ovf;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // filter in registers, bias in LDS, before the counted waits start
     issue_patch(tile, smem);
     int cur = 0;
@@ -334,14 +339,16 @@ __global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoo
                         best, *(const u16x8_t*)(ctile + (yy * TW + xx) * 128 + ((c ^ (xx & 7)) << 4)));
                 }
             gstore16(a.y + ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c * 8, __builtin_bit_cast(u32x4_t, best));
+            ovf.see(__builtin_bit_cast(u32x4_t, best));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pooling reads retired before the next tile's barrier
         cur ^= 1;
     }
+    ovf.flush(a.ovf);
 }
 
 int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
-                     int OH, int OW, int dtype, hipStream_t stream) {
+                     int OH, int OW, int dtype, hipStream_t stream, int* ovf) {
     if ((size_t)B * H2 * W2 * 32 >= (1ull << 31))
         return fail(DIR_ERR_INVALID, "stem_pool: input exceeds 2^31 bytes; lower the batch");
     StemPoolArgs a;
@@ -353,6 +360,7 @@ int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y,
     a.PH = (OH - 1) / 2 + 1;
     a.PW = (OW - 1) / 2 + 1;
     a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
+    a.ovf = ovf;
     const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "stem_pool: bad dtype");
     const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting (read per launch: the tests flip it)

@@ -64,6 +64,7 @@ SIGNATURES = {
     'dir_conv_variant_name': (c_int, [c_int, c_char_p, c_int]),
     'dir_conv_bn_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14
                         + [c_void_p]),
+    'dir_engine_overflow': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'dir_conv_heuristic': (c_int, [c_int] * 12 + [c_char_p, c_int, POINTER(c_int)]),
     'dir_conv_bn_act_splitk': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 15 +
                                [c_void_p, c_size_t, POINTER(c_int), c_void_p]),

@@ -102,9 +102,21 @@ def extract_sharded(extract_fn, dataset, trfs, net, width=None, **kw):
         return extract_fn(dataset, trfs, net, **kw)
     n = len(dataset)
     lo, hi = shard_range(n)
+    D = width or (net._head_in_dim() if getattr(net, 'without_fc', False) else net.out_dim)
+    dev = 'cuda' if net.iscuda else 'cpu'
+    local, err = None, None
     if hi > lo:
-        local = extract_fn(SubDataset(dataset, lo, hi), trfs, net, **kw)
-    else:
-        D = width or (net._head_in_dim() if getattr(net, 'without_fc', False) else net.out_dim)
-        local = torch.empty((0, D), dtype=torch.float32, device='cuda' if net.iscuda else 'cpu')
+        try:
+            local = extract_fn(SubDataset(dataset, lo, hi), trfs, net, **kw)
+        except FloatingPointError as e:     # (fp16 overflow on this rank's shard, test_dir._check_finite)
+            err = e
+    if local is None:
+        local = torch.zeros((hi - lo if err else 0, D), dtype=torch.float32, device=dev)
+    # every rank must reach the collective: a rank that raised on its own would leave the others blocked in
+    # the all-gather until the RCCL timeout.  Agree on the failure first, then raise everywhere.
+    bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
+    torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+    if int(bad.item()):
+        raise err if err else FloatingPointError('another rank reported non-finite descriptors / fp16 overflow '
+                                                 'on its shard (see its log); run with DIRTORCH_AMD_DTYPE=bf16')
     return allgather_rows(local, n)

@@ -317,6 +317,16 @@ class ResNet_RMAC(object):
         assert (oh.value, ow.value, oc.value) == (h, w, self.trunk_dim)
         return feat
 
+    def overflowed(self):
+        """True when any kernel stored an fp16 inf / NaN since the last query (dir_engine_overflow: one
+        device word, read and cleared; synchronises the current stream).  The reference runs in fp32 and
+        cannot overflow (resnet.py:67-87); bf16 shares fp32's range and never reports."""
+        if self._engine is None or self._dirty:
+            return False
+        flag = ctypes.c_int()
+        call('dir_engine_overflow', self._engine, stream_ptr(), ctypes.byref(flag))
+        return bool(flag.value)
+
     # ---- profiling ---------------------------------------------------------------------------
     def set_profiling(self, enabled):
         if self._dirty or self._engine is None:

@@ -53,11 +53,17 @@ def expand_descriptors(descs, db=None, alpha=0, k=0):
 
 
 def _check_finite(feats, net):
-    """fp16 activations overflow at 65504: a checkpoint whose activations leave that range shows up
-    as inf/NaN descriptors.  One reduction + sync per extraction pass."""
-    if feats.numel() and not bool(torch.isfinite(feats).all()):
-        raise FloatingPointError('non-finite descriptors with compute dtype %s: activations left the 16-bit range; '
-                                 'run with DIRTORCH_AMD_DTYPE=bf16' % getattr(net, 'compute_dtype', '?'))
+    """fp16 activations overflow at 65504 (the reference computes in fp32 and cannot).  Two checks, one
+    sync per extraction pass: the engine's overflow word - every kernel that stores an fp16 inf / NaN
+    sets it, so an overflow deep inside the trunk that a later ReLU flushes to zero is still caught -
+    and the descriptors themselves (inf / NaN weights in the checkpoint show up here in any dtype)."""
+    overflow = getattr(net, 'overflowed', lambda: False)()
+    if overflow or (feats.numel() and not bool(torch.isfinite(feats).all())):
+        raise FloatingPointError('%s with compute dtype %s: activations left the 16-bit range; run with '
+                                 'DIRTORCH_AMD_DTYPE=bf16 (fp32 range, 8-bit mantissa) or DIRTORCH_AMD_DTYPE=f32 '
+                                 '(the reference\'s arithmetic)'
+                                 % ('fp16 overflow inside the trunk' if overflow else 'non-finite descriptors',
+                                    getattr(net, 'compute_dtype', '?')))
     return feats
 
 

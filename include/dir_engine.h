@@ -110,6 +110,14 @@ int dir_forward(dir_engine* e, const void* img, int B, int H, int W, int img_for
 int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, int img_format,
                          void* feat_out, int* h, int* w, int* c,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* fp16 range check.  The reference computes in fp32 and cannot overflow (dirtorch/nets/backbones/resnet.py:67-87);
+ * DIR_FP16 storage saturates at 65504.  Every kernel that packs fp32 sums into fp16 for a store ORs into an
+ * engine-owned device word when it stores an inf / NaN - the first overflow of a forward is always such a store,
+ * so a later ReLU (hardware max drops NaN operands) or a fused consumer cannot hide it.  This call synchronises
+ * `stream`, returns the word in *overflowed (0 / 1) and clears it; the word is sticky across forwards until then.
+ * Always 0 for DIR_BF16 (fp32's exponent range).  The host mirror raises FloatingPointError naming the
+ * DIRTORCH_AMD_DTYPE switch (dirtorch_amd/test_dir.py _check_finite). */
+int dir_engine_overflow(dir_engine* e, void* stream, int* overflowed);
 
 /* Tile-variant selection for the implicit-GEMM convolutions: run every admissible variant on each
  * layer shape of a B x H x W forward and keep the fastest (synchronises).  Optional. */

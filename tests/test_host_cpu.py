@@ -190,6 +190,17 @@ def _worker(rank, world, port, ns, out):
         lo, hi = dd.shard_range(n)
         res[('gather', n)] = dd.allgather_rows(_fake_descs(lo, hi), n)
         res[('extract', n)] = dd.extract_sharded(_fake_extract, _FakeDB(n), '', _FakeNet())
+    # a failure on ONE rank's shard (fp16 overflow, test_dir._check_finite) must surface on EVERY rank before
+    # the collective, not leave the healthy ranks blocked in it
+    def _overflowing_extract(dataset, trfs, net, **kw):
+        if dataset.get_key(0) == 0:          # rank 0's shard
+            raise FloatingPointError('fp16 overflow inside the trunk with compute dtype fp16')
+        return _fake_extract(dataset, trfs, net, **kw)
+    try:
+        dd.extract_sharded(_overflowing_extract, _FakeDB(10), '', _FakeNet())
+        res['overflow'] = 'no error'
+    except FloatingPointError as e:
+        res['overflow'] = str(e)
     out[rank] = res
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -209,6 +220,8 @@ def test_allgather_equals_single_process_concat_gloo_ws2():
         for r in (0, 1):
             assert torch.equal(res[r][('gather', n)], full), (n, r)       # bit-for-bit
             assert torch.equal(res[r][('extract', n)], full), (n, r)
+    assert 'fp16 overflow inside the trunk' in res[0]['overflow'] and 'another rank' in res[1]['overflow'], \
+        (res[0]['overflow'], res[1]['overflow'])
 
 
 def test_single_process_passthrough():

@@ -397,3 +397,52 @@ def test_fp16_overflow_is_reported_not_returned(tmp_path):
             with pytest.raises(FloatingPointError) as ei:
                 td.extract_image_features(db, '', net, threads=0)
             assert 'DIRTORCH_AMD_DTYPE=bf16' in str(ei.value)
+
+
+def test_fp16_overflow_hidden_by_a_later_relu_is_still_reported(tmp_path):
+    """An overflow planted in layer2: a huge bn1 gain makes conv1's post-ReLU output +inf in fp16, conv2 then
+    sums inf - inf = NaN, and its fused ReLU - a hardware max, which returns the non-NaN operand - flushes
+    the NaNs to 0: the descriptors come out FINITE and wrong.  The engine's overflow word (every kernel that
+    stores an fp16 inf / NaN sets it, dir_engine_overflow) must still turn that into an error; bf16 (fp32's
+    exponent range) runs clean.  The reference computes in fp32 and cannot overflow
+    (dirtorch/nets/backbones/resnet.py:67-87)."""
+    import dir_oracle as O
+    from dirtorch_amd import datasets, nets
+    from dirtorch_amd import test_dir as td
+    names = ['a.png', 'b.png']
+    save_images(str(tmp_path / 'imgs'), names, [(96, 96), (96, 96)], 7)
+    (tmp_path / 'list.txt').write_text('\n'.join(names) + '\n')
+    db = datasets.create('ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'))
+    x = O.synth_images(5, 2, 96, 96).cuda()
+    for arch, key in (('resnet50', 'layer2.0.bn1.weight'), ('resnet18', 'layer2.0.bn1.weight')):
+        sd = O.synth_state_dict(arch, seed=7, gemp=3.0)
+        sd[key] = sd[key] * 1e6
+        for dtype in ('fp16', 'bf16'):
+            net = nets.create_model(arch + '_rmac', pretrained='')
+            net.load_state_dict(sd)
+            net.compute_dtype = dtype
+            net.cuda().eval()
+            assert net.overflowed() is False            # nothing ran yet
+            d = net(x)
+            if dtype == 'bf16':
+                assert torch.isfinite(d).all() and net.overflowed() is False
+                assert torch.isfinite(td.extract_image_features(db, '', net, threads=0)).all()
+                continue
+            hidden = bool(torch.isfinite(d).all())
+            print('\n[overflow] %s fp16: descriptors finite = %s' % (arch, hidden))
+            assert net.overflowed() is True, 'an fp16 inf was stored in layer2 and nobody noticed'
+            assert net.overflowed() is False            # read-and-clear
+            with pytest.raises(FloatingPointError) as ei:
+                td.extract_image_features(db, '', net, threads=0)
+            assert 'DIRTORCH_AMD_DTYPE=bf16' in str(ei.value)
+            if hidden:
+                assert 'fp16 overflow inside the trunk' in str(ei.value)
+    # a healthy checkpoint never trips the word (fp16, every kernel family of a 1024^2 batch)
+    sd = O.synth_state_dict('resnet50', seed=7)
+    net = nets.create_model('resnet50_rmac', pretrained='')
+    net.load_state_dict(sd)
+    net.compute_dtype = 'fp16'
+    net.cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    net(torch.randint(0, 256, (8, 1024, 1024, 3), generator=g, dtype=torch.uint8, device='cuda'))
+    assert net.overflowed() is False
