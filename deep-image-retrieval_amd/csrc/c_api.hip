@@ -128,6 +128,24 @@ int dir_forward(dir_engine* e, const void* img, int B, int H, int W, int fmt, fl
     DIR_CATCH
 }
 
+int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H,
+                        int W, int Cin, int Cout, int R, int S, int stride, int pad, int OH, int OW, int relu,
+                        void* stream) {
+    DIR_TRY
+    if (!x || !w || !bias || !y) return fail(DIR_ERR_INVALID, "conv_bn_act_f32: null argument");
+    if (OH != (H + 2 * pad - R) / stride + 1 || OW != (W + 2 * pad - S) / stride + 1)
+        return fail(DIR_ERR_INVALID, "conv_bn_act_f32: OH/OW do not match the conv geometry");
+    ConvF32Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.relu = relu;
+    a.M = B * OH * OW;
+    a.Ktot = R * S * Cin;
+    return conv_f32_launch(a, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_engine_overflow(dir_engine* e, void* stream, int* overflowed) {
     DIR_TRY
     if (!e || !overflowed) return fail(DIR_ERR_INVALID, "overflow: null argument");
@@ -148,6 +166,7 @@ int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, in
 int dir_engine_autotune(dir_engine* e, int B, int H, int W, void* ws, size_t ws_bytes, void* stream) {
     DIR_TRY
     if (!e) return fail(DIR_ERR_INVALID, "autotune: null engine");
+    if (e->dtype == DIR_F32) return DIR_OK;   // the strict path has one kernel per conv: nothing to choose
     const bool was_prof = e->profiling;
     e->profiling = false;
     e->tuning = true;

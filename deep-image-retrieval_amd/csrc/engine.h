@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 
+#include "conv_f32.h"
 #include "conv_igemm.h"
 #include "pointwise.h"
 
@@ -22,6 +23,7 @@ struct ConvLayer {
     bool relu = false;
     bool stem = false;    // packed as the 4x4 s1 space-to-depth form (Cin 16)
     uint16_t* d_w = nullptr;
+    float* d_wf = nullptr;   // DIR_F32 (strict path, conv_f32.hip): the same layout in fp32; d_w stays null
     float* d_bias = nullptr;
     // conv3 of a stage's first block whose downsample qualifies (conv_c3c1.hip, DS form): this conv's
     // weights with the downsample's appended along K, and the sum of the two folded-BN biases
@@ -82,6 +84,11 @@ struct dir_engine {
     int plan(int B, int H, int W, dir::Plan* p) const;
     int forward(const void* img, int B, int H, int W, int fmt, float* desc_out, void* feat_out,
                 int* fh, int* fw, int* fc, void* ws, size_t ws_bytes, hipStream_t stream);
+    // the strict fp32 path (conv_f32.hip): the reference's op sequence, nothing fused
+    int forward_f32(const void* img, int B, int H, int W, int fmt, float* desc_out, void* feat_out, int* fh, int* fw,
+                    int* fc, char* base, const dir::Plan& p, hipStream_t stream);
+    int run_conv_f32(dir::ConvLayer& L, const float* x, const float* res, float* y, int B, int H, int W, int OH, int OW,
+                     hipStream_t stream);
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
                  int H, int W, int OH, int OW, hipStream_t stream);
     // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes

@@ -127,7 +127,7 @@ static const HostTensor* find(const std::map<std::string, HostTensor>& st, const
 }
 
 int dir_engine::finalize(int dt) {
-    if (dt != DIR_BF16 && dt != DIR_FP16) return fail(DIR_ERR_INVALID, "finalize: bad dtype");
+    if (dt != DIR_BF16 && dt != DIR_FP16 && dt != DIR_F32) return fail(DIR_ERR_INVALID, "finalize: bad dtype");
     DIR_HIP_CHECK(hipSetDevice(device));
     release();
     dtype = dt;
@@ -157,11 +157,13 @@ int dir_engine::finalize(int dt) {
             scale[o] = g->data[o] * inv;
             bias[o] = bt->data[o] - mu->data[o] * scale[o];
         }
-        std::vector<uint16_t> packed;
+        // packed in fp32 first ([Cout][R][S][Cin], BatchNorm scale folded in with one fp32 multiply); the
+        // 16-bit formats round that, the strict path (DIR_F32, conv_f32.hip) uploads it as is
+        std::vector<float> packed;
         if (L.stem) {
             // 7x7 s2 p3 over 3 channels == 4x4 s1 (pad 2 top/left) over the 2x2 space-to-depth
             // image with 12 (+4 zero) channels: tap r = 2R + dy - 1, s = 2S + dx - 1.
-            packed.assign((size_t)L.Cout * 4 * 4 * 16, 0);
+            packed.assign((size_t)L.Cout * 4 * 4 * 16, 0.f);
             for (int o = 0; o < L.Cout; ++o)
                 for (int R = 0; R < 4; ++R)
                     for (int S = 0; S < 4; ++S)
@@ -172,8 +174,7 @@ int dir_engine::finalize(int dt) {
                                 for (int c = 0; c < 3; ++c) {
                                     const float v =
                                         w->data[(((size_t)o * 3 + c) * 7 + r) * 7 + s] * scale[o];
-                                    packed[(((size_t)o * 4 + R) * 4 + S) * 16 + (dy * 2 + dx) * 3 + c] =
-                                        to16(v);
+                                    packed[(((size_t)o * 4 + R) * 4 + S) * 16 + (dy * 2 + dx) * 3 + c] = v;
                                 }
                             }
         } else {
@@ -184,15 +185,22 @@ int dir_engine::finalize(int dt) {
                         for (int s = 0; s < L.S; ++s) {
                             const float v =
                                 w->data[(((size_t)o * L.Cin + c) * L.R + r) * L.S + s] * scale[o];
-                            packed[(((size_t)o * L.R + r) * L.S + s) * L.Cin + c] = to16(v);
+                            packed[(((size_t)o * L.R + r) * L.S + s) * L.Cin + c] = v;
                         }
         }
-        DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed.size() * 2));
-        DIR_HIP_CHECK(hipMemcpy(L.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_bias, L.Cout * 4));
         DIR_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), L.Cout * 4, hipMemcpyHostToDevice));
         L.tuned.clear();
-        L.h_w.swap(packed);
+        if (dt == DIR_F32) {
+            DIR_HIP_CHECK(hipMalloc((void**)&L.d_wf, packed.size() * 4));
+            DIR_HIP_CHECK(hipMemcpy(L.d_wf, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+            continue;
+        }
+        std::vector<uint16_t> packed16(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) packed16[i] = to16(packed[i]);
+        DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed16.size() * 2));
+        DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
+        L.h_w.swap(packed16);
         L.h_bias.swap(bias);
     }
     // First block of every stage (bottleneck nets): the residual is a 1x1 downsample conv of the block
@@ -201,7 +209,7 @@ int dir_engine::finalize(int dt) {
     // materialised: conv_c3c1's DS form (layer1: 64 + 64 channels, stride 1) or the two-source form of the
     // implicit-GEMM kernel (layers 2-4, stride 2).
     for (const BlockDef& bd : blocks) {
-        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0) continue;
+        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0 || dt == DIR_F32) continue;
         ConvLayer& c3 = convs[bd.conv3];
         const ConvLayer& ds = convs[bd.down];
         if (ds.R != 1 || ds.S != 1 || ds.pad != 0 || ds.Cout != c3.Cout || ds.Cin % 64 != 0 || c3.Cin % 64 != 0) continue;
@@ -256,6 +264,8 @@ int dir_engine::finalize(int dt) {
 void dir_engine::release() {
     for (ConvLayer& L : convs) {
         if (L.d_w) (void)hipFree(L.d_w);
+        if (L.d_wf) (void)hipFree(L.d_wf);
+        L.d_wf = nullptr;
         if (L.d_bias) (void)hipFree(L.d_bias);
         if (L.d_w_ds) (void)hipFree(L.d_w_ds);
         if (L.d_bias_ds) (void)hipFree(L.d_bias_ds);
@@ -294,38 +304,39 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->OW1 = conv_out(W, 7, 2, 3);
     p->PH = conv_out(p->OH1, 3, 2, 1);
     p->PW = conv_out(p->OW1, 3, 2, 1);
+    const size_t es = dtype == DIR_F32 ? 4 : 2;   // bytes per stored activation
     size_t io = 0, t1 = 0, t2 = 0, ds = 0, x4 = 0;
     int h = p->PH, w = p->PW;
-    io = (size_t)B * h * w * 64 * 2;
+    io = (size_t)B * h * w * 64 * es;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
         const BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
         const ConvLayer& c1 = convs[bd.conv1];
         const ConvLayer& cl = convs[desc.bottleneck ? bd.conv3 : bd.conv2];
         if (desc.bottleneck) {
-            t1 = std::max(t1, (size_t)B * h * w * c1.Cout * 2);
-            t2 = std::max(t2, (size_t)B * oh * ow * convs[bd.conv2].Cout * 2);
+            t1 = std::max(t1, (size_t)B * h * w * c1.Cout * es);
+            t2 = std::max(t2, (size_t)B * oh * ow * convs[bd.conv2].Cout * es);
         } else {
-            t1 = std::max(t1, (size_t)B * oh * ow * c1.Cout * 2);
+            t1 = std::max(t1, (size_t)B * oh * ow * c1.Cout * es);
         }
-        if (bd.down >= 0) ds = std::max(ds, (size_t)B * oh * ow * convs[bd.down].Cout * 2);
-        io = std::max(io, (size_t)B * oh * ow * cl.Cout * 2);
+        if (bd.down >= 0) ds = std::max(ds, (size_t)B * oh * ow * convs[bd.down].Cout * es);
+        io = std::max(io, (size_t)B * oh * ow * cl.Cout * es);
         h = oh;
         w = ow;
         if ((int)bi == x4_block) {  // FPN heads keep x4; the lateral path reuses t1 / t2 / a ping-pong buffer
-            x4 = (size_t)B * h * w * x4_dim * 2;
+            x4 = (size_t)B * h * w * x4_dim * es;
             t2 = std::max(t2, x4);
         }
     }
-    if (conv1x5 >= 0) t1 = std::max(t1, (size_t)B * h * w * x4_dim * 2);
+    if (conv1x5 >= 0) t1 = std::max(t1, (size_t)B * h * w * x4_dim * es);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
         off += align_up(bytes);
         return o;
     };
-    p->s2d = take((size_t)B * p->H2 * p->W2 * 16 * 2);
-    p->stem = take((size_t)B * p->OH1 * p->OW1 * 64 * 2);
+    p->s2d = take((size_t)B * p->H2 * p->W2 * 16 * es);
+    p->stem = take((size_t)B * p->OH1 * p->OW1 * 64 * es);
     p->bufA = take(io);
     p->bufB = take(io);
     p->t1 = take(t1);
@@ -594,6 +605,8 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
                                            " bytes, got " + std::to_string(ws_bytes));
     if (((uintptr_t)ws & 255) != 0) return fail(DIR_ERR_INVALID, "workspace must be 256-byte aligned");
     char* base = (char*)ws;
+    splitk_scratch = (float*)(base + p.splitk);
+    if (dtype == DIR_F32) return forward_f32(img, B, H, W, fmt, desc_out, feat_out, fh, fw, fc, base, p, stream);
     uint16_t* s2d = (uint16_t*)(base + p.s2d);
     uint16_t* stem = (uint16_t*)(base + p.stem);
     uint16_t* cur = (uint16_t*)(base + p.bufA);
@@ -603,7 +616,6 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     uint16_t* ds = (uint16_t*)(base + p.ds);
     float* pooled = (float*)(base + p.pooled);
     float* fcout = (float*)(base + p.fcout);
-    splitk_scratch = (float*)(base + p.splitk);
 
     // 1. image -> space-to-depth NHWC16
     if (img) {
@@ -772,6 +784,172 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         if (rc != DIR_OK) return rc;
         rc = gemm_nt_f32(d_fc_w, head_dim, pooled, head_dim, fcout, D, D, B, head_dim, nullptr,
                          d_fc_b, nullptr, stream, splitk_scratch, kSplitKMaxBytes);   // the convs are done with it
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    } else {
+        fcout = pooled;
+    }
+    if (!classifier) {
+        rc = l2norm_rows(fcout, B, D, 1e-12f, stream);
+        if (rc != DIR_OK) return rc;
+    }
+    DIR_HIP_CHECK(hipMemcpyAsync(desc_out, fcout, (size_t)B * D * 4, hipMemcpyDeviceToDevice, stream));
+    return DIR_OK;
+}
+
+// ---- the strict path: fp32 storage, fp32 matrix cores (conv_f32.hip) --------------------------------------------
+// The reference's op sequence one to one (ResNet.forward resnet.py:157-174, Bottleneck.forward :67-87,
+// ResNet_RMAC.forward rmac_resnet.py:39-69), eval-mode BatchNorm folded into fp32 weights, bias / residual / ReLU in
+// the conv epilogue, nothing fused across layers.  Differences from the reference's fp32 CPU result are summation
+// order only.
+int dir_engine::run_conv_f32(ConvLayer& L, const float* x, const float* res, float* y, int B, int H, int W, int OH,
+                             int OW, hipStream_t stream) {
+    ConvF32Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w = L.d_wf;
+    a.bias = L.d_bias;
+    a.res = res;
+    a.y = y;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.OH = OH;
+    a.OW = OW;
+    a.Cout = L.Cout;
+    if (L.stem) {  // (H, W) is the space-to-depth grid
+        a.Cin = 16;
+        a.R = a.S = 4;
+        a.stride = 1;
+        a.pad = 2;
+    } else {
+        a.Cin = L.Cin;
+        a.R = L.R;
+        a.S = L.S;
+        a.stride = L.stride;
+        a.pad = L.pad;
+    }
+    a.relu = L.relu ? 1 : 0;
+    a.M = B * OH * OW;
+    a.Ktot = a.R * a.S * a.Cin;
+    const double macs = (double)a.M * L.Cout * (double)(L.R * L.S * L.Cin);
+    const double bytes = 4.0 * ((double)B * H * W * a.Cin + (double)a.M * L.Cout * (res ? 2 : 1) + (double)L.Cout * a.Ktot);
+    int rc = DIR_OK;
+    if (profiling && !prof_paused)
+        rc = prof_begin(L.name, std::string("conv_f32<") + (L.Cout <= 64 ? "128x64" : "128x128") + ">", 2.0 * macs, bytes,
+                        stream);
+    if (rc != DIR_OK) return rc;
+    rc = conv_f32_launch(a, stream);
+    if (rc != DIR_OK) return rc;
+    return prof_end(stream);
+}
+
+int dir_engine::forward_f32(const void* img, int B, int H, int W, int fmt, float* desc_out, void* feat_out, int* fh,
+                            int* fw, int* fc, char* base, const Plan& p, hipStream_t stream) {
+    float* s2d = (float*)(base + p.s2d);
+    float* stem = (float*)(base + p.stem);
+    float* t1 = (float*)(base + p.t1);
+    float* t2 = (float*)(base + p.t2);
+    float* ds = (float*)(base + p.ds);
+    float* pooled = (float*)(base + p.pooled);
+    float* fcout = (float*)(base + p.fcout);
+    float* const pp[2] = {(float*)(base + p.bufA), (float*)(base + p.bufB)};
+    if (!img) return fail(DIR_ERR_INVALID, "autotune has nothing to choose in the fp32 path");
+    int rc = prof_begin("prep_input", "prep_input_f32", 0,
+                        (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) + (double)B * p.H2 * p.W2 * 64, stream);
+    if (rc != DIR_OK) return rc;
+    rc = prep_input_f32(img, fmt, desc.mean, desc.std, s2d, B, H, W, stream);
+    if (rc != DIR_OK) return rc;
+    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    rc = run_conv_f32(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
+    if (rc != DIR_OK) return rc;
+    float* cur = pp[0];
+    rc = prof_begin("maxpool", "maxpool_f32", 0, 4.0 * ((double)B * p.OH1 * p.OW1 * 64 + (double)B * p.PH * p.PW * 64),
+                    stream);
+    if (rc != DIR_OK) return rc;
+    rc = maxpool_3x3s2_f32(stem, cur, B, p.OH1, p.OW1, 64, stream);
+    if (rc != DIR_OK) return rc;
+    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+
+    float* x4 = nullptr;
+    int h = p.PH, w = p.PW, h4 = 0, w4 = 0;
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        BlockDef& bd = blocks[bi];
+        const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
+        const bool keep = (int)bi == x4_block;
+        float* nxt = keep ? (float*)(base + p.x4) : (cur == pp[0] ? pp[1] : pp[0]);
+        const float* resid = cur;
+        if (bd.down >= 0) {
+            rc = run_conv_f32(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            resid = ds;
+        }
+        if (desc.bottleneck) {
+            rc = run_conv_f32(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_f32(convs[bd.conv2], t1, nullptr, t2, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_f32(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+        } else {
+            rc = run_conv_f32(convs[bd.conv1], cur, nullptr, t1, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_f32(convs[bd.conv2], t1, resid, nxt, B, oh, ow, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+        }
+        cur = nxt;
+        h = oh;
+        w = ow;
+        if (keep) {
+            x4 = cur;
+            h4 = h;
+            w4 = w;
+        }
+    }
+    if (feat_out) {
+        DIR_HIP_CHECK(hipMemcpyAsync(feat_out, cur, (size_t)B * h * w * feat_dim * 4, hipMemcpyDeviceToDevice, stream));
+        if (fh) *fh = h;
+        if (fw) *fw = w;
+        if (fc) *fc = feat_dim;
+    }
+    if (!desc_out) return DIR_OK;
+
+    const bool fpn = x4 != nullptr;
+    const bool classifier = desc.head == DIR_HEAD_CLASSIFIER;
+    if (fpn) {
+        const float* c4 = x4;
+        if (conv1x5 >= 0) {
+            float* sum = cur == pp[0] ? pp[1] : pp[0];
+            rc = run_conv_f32(convs[conv1x5], cur, nullptr, t1, B, h, w, h, w, stream);
+            if (rc != DIR_OK) return rc;
+            rc = upsample_add_f32(x4, t1, sum, B, h4, w4, h, w, x4_dim, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_f32(convs[conv3c4], sum, nullptr, t2, B, h4, w4, h4, w4, stream);
+            if (rc != DIR_OK) return rc;
+            c4 = t2;
+        }
+        rc = global_pool_f32(c4, pooled, head_dim, B, h4, w4, x4_dim, DIR_POOL_GEM, gem_p4, 1e-6f, 0.f, stream);
+        if (rc != DIR_OK) return rc;
+    }
+    rc = prof_begin(fpn ? "adpoolx5" : "adpool", "global_pool_f32", 0,
+                    (double)B * h * w * feat_dim * 4 + (double)B * feat_dim * 4, stream);
+    if (rc != DIR_OK) return rc;
+    rc = global_pool_f32(cur, pooled + (fpn ? x4_dim : 0), head_dim, B, h, w, feat_dim,
+                         classifier ? DIR_POOL_AVG : desc.pooling, gem_p, 1e-6f,
+                         (fpn || classifier) ? 0.f : desc.center_bias, stream);
+    if (rc != DIR_OK) return rc;
+    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    if (desc.norm_features && !classifier) {
+        rc = l2norm_rows(pooled, B, head_dim, 1e-12f, stream);
+        if (rc != DIR_OK) return rc;
+    }
+    const int D = desc.without_fc ? head_dim : desc.out_dim;
+    if (!desc.without_fc) {
+        rc = prof_begin("fc", "gemm_nt_f32", 2.0 * B * head_dim * (double)D,
+                        4.0 * ((double)D * head_dim + (double)B * (head_dim + D)), stream);
+        if (rc != DIR_OK) return rc;
+        rc = gemm_nt_f32(d_fc_w, head_dim, pooled, head_dim, fcout, D, D, B, head_dim, nullptr, d_fc_b, nullptr, stream,
+                         splitk_scratch, kSplitKMaxBytes);
         if (rc != DIR_OK) return rc;
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
     } else {

@@ -59,6 +59,25 @@ def pack_stem_weight(w_oihw, dtype=torch.bfloat16):
     return out.to(dtype)
 
 
+def conv_bn_act_f32(x, w, bias, res=None, stride=1, pad=0, relu=True):
+    """The strict path's convolution (dir_conv_bn_act_f32, conv_f32.hip): x NHWC [B,H,W,Cin] fp32,
+    w [Cout,R,S,Cin] fp32, bias fp32 [Cout], res NHWC fp32 or None -> NHWC [B,OH,OW,Cout] fp32."""
+    _need_cuda(x, w, bias, res)
+    for t in (x, w, bias, res):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError('fp32 tensors expected')
+    B, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w.shape
+    if Cin2 != Cin:
+        raise ValueError('Cin mismatch')
+    OH = (H + 2 * pad - R) // stride + 1
+    OW = (W + 2 * pad - S) // stride + 1
+    y = torch.empty(B, OH, OW, Cout, dtype=torch.float32, device=x.device)
+    call('dir_conv_bn_act_f32', ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), B, H, W, Cin, Cout, R, S, stride, pad,
+         OH, OW, int(bool(relu)), stream_ptr())
+    return y
+
+
 def conv_bn_act(x, w, bias, res=None, stride=1, pad=0, relu=True, out_hw=None, variant=-1,
                 naive=False, ksplit=None):
     """x NHWC [B,H,W,Cin] 16-bit, w [Cout,R,S,Cin] 16-bit, bias fp32 [Cout] -> NHWC [B,OH,OW,Cout].

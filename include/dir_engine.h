@@ -13,7 +13,8 @@
  *   - all tensor pointers are DEVICE pointers owned by the caller unless the name says host_;
  *     `stream` is a hipStream_t passed as void* (NULL = the default stream).  Nothing here
  *     synchronises the device except dir_engine_finalize and the profiling getters.
- *   - activations are NHWC, 16-bit (bf16 or fp16, chosen at finalize); accumulation is fp32.
+ *   - activations are NHWC, 16-bit (bf16 or fp16) or fp32 (DIR_F32, the strict path), chosen at finalize;
+ *     accumulation is always fp32.
  *   - the engine owns only its packed weights; the caller owns images, descriptors and workspace.
  *   - a handle is not re-entrant: one handle per device, one calling thread at a time
  *     (the reference calls net(x) from one thread, dirtorch/test_dir.py:67-81).
@@ -38,9 +39,14 @@ typedef enum dir_status {
     DIR_ERR_NOMEM = -6
 } dir_status;
 
+/* Storage format of activations and weights, chosen at dir_engine_finalize (the C ABI has no default; the Python
+ * host mirror defaults to fp16, bench.py measures bf16 = BASELINE configs[1] and reports the other two beside it).
+ * Accumulation is fp32 in all three. */
 typedef enum dir_dtype {
-    DIR_BF16 = 0,             /* bf16 activations/weights, fp32 accumulate (default) */
-    DIR_FP16 = 1              /* fp16 activations/weights, fp32 accumulate           */
+    DIR_BF16 = 0,             /* bf16 storage, bf16 MFMA: fp32's exponent range, 8-bit mantissa               */
+    DIR_FP16 = 1,             /* fp16 storage, fp16 MFMA: 11-bit mantissa, saturates at 65504 (dir_engine_overflow) */
+    DIR_F32 = 2               /* STRICT: fp32 storage and products on the fp32 matrix cores (conv_f32.hip) - the
+                                 reference's own arithmetic up to summation order; ~1/8 of the 16-bit throughput */
 } dir_dtype;
 
 typedef enum dir_img_format {
@@ -105,11 +111,17 @@ int dir_workspace_bytes(const dir_engine* e, int B, int H, int W, size_t* bytes)
  * view, rmac_resnet.py:64.)  img: B x 3 x H x W fp32 or B x H x W x 3 uint8, per img_format. */
 int dir_forward(dir_engine* e, const void* img, int B, int H, int W, int img_format,
                 float* desc_out, void* workspace, size_t workspace_bytes, void* stream);
-/* Same, but also returns the trunk feature map (NHWC 16-bit, B x h x w x C) for block-level
+/* Same, but also returns the trunk feature map (NHWC, B x h x w x C, 16-bit or fp32 per the dtype) for block-level
  * parity tests against ResNet.forward (dirtorch/nets/backbones/resnet.py:157-174). */
 int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, int img_format,
                          void* feat_out, int* h, int* w, int* c,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Strict-path convolution (DIR_F32): y = act(conv(x, w) + bias (+ res)), everything fp32 NHWC / [Cout][R][S][Cin],
+ * Cin % 4 == 0, Cout % 4 == 0; products on v_mfma_f32_32x32x2_f32 (an fmaf chain).  Replaces Conv2d + eval BatchNorm
+ * (+ residual add) (+ ReLU) of dirtorch/nets/backbones/resnet.py:56-63,70-85 without any rounding of operands. */
+int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H,
+                        int W, int Cin, int Cout, int R, int S, int stride, int pad, int OH, int OW, int relu,
+                        void* stream);
 /* fp16 range check.  The reference computes in fp32 and cannot overflow (dirtorch/nets/backbones/resnet.py:67-87);
  * DIR_FP16 storage saturates at 65504.  Every kernel that packs fp32 sums into fp16 for a store ORs into an
  * engine-owned device word when it stores an inf / NaN - the first overflow of a forward is always such a store,

@@ -164,7 +164,7 @@ def test_test_dir_cli_roxford_protocol(tmp_path, monkeypatch, dtype):
 
 
 @pytest.mark.parametrize('ckpt', ['synthetic', 'calibrated'])
-@pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16', 'f32'])
 def test_extract_whiten_rank_map_parity(dtype, ckpt):
     """extraction -> PCA whitening -> similarity -> revisitop mAP on 400 images / 25 queries with
     planted near-duplicates, on two checkpoints:
@@ -180,7 +180,8 @@ def test_extract_whiten_rank_map_parity(dtype, ckpt):
     bf16: no fixed number is honest - an IDEAL bf16-storage implementation (the oracle's quant=
     emulation of the engine's storage points) is itself 2e-4 / 1e-3 away on the calibrated checkpoint -
     so every bf16 allowance is 3 x the emulation's own distance from fp32, computed here on the same
-    data, and the engine must also sit within that distance OF the emulation."""
+    data, and the engine must also sit within that distance OF the emulation.
+    f32 (the strict path, conv_f32.hip): the stated numbers on BOTH checkpoints, no allowance of any kind."""
     import dir_oracle as O
     from dirtorch_amd import nets
     from dirtorch_amd.utils import common
@@ -203,7 +204,8 @@ def test_extract_whiten_rank_map_parity(dtype, ckpt):
     def oracle(quant=None):
         return torch.cat([O.rmac_forward(sd, 'resnet18', x[i:i + 50], quant=quant) for i in range(0, N, 50)]).numpy()
 
-    ref, emu = oracle(), oracle(dtype)
+    ref = oracle()
+    emu = ref if dtype == 'f32' else oracle(dtype)
     net = nets.create_model('resnet18_rmac', pretrained='')
     net.load_state_dict(sd)
     net.compute_dtype = dtype
@@ -228,7 +230,7 @@ def test_extract_whiten_rank_map_parity(dtype, ckpt):
     print('\n[pipeline] %s %s: mean cosine of unrelated images %.4f | 1-cos raw: engine %.2e ideal-16bit %.2e | '
           'whitened: engine %.2e ideal %.2e | max |dmAP|: engine %.2e ideal %.2e | mAP-medium %.3f'
           % (ckpt, dtype, pair.mean(), e_raw, i_raw, e_w, i_w, d_map, i_map, m_ref['mAP-medium']))
-    if dtype == 'fp16' and ckpt == 'calibrated':            # the north-star numbers, as stated
+    if dtype == 'f32' or (dtype == 'fp16' and ckpt == 'calibrated'):            # the north-star numbers, as stated
         assert e_raw < 1e-4 and e_w < 1e-4 and d_map < 1e-3, (e_raw, e_w, d_map)
     else:
         assert e_raw < max(1e-4, 3 * i_raw), (e_raw, i_raw)
