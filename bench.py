@@ -56,12 +56,16 @@ def cpu_allotted():
     return avail
 
 
-def cpu_baseline(arch, size, budget_s):
-    """CPU oracle forward, batch 1 (the reference's default path, test_dir.py:52-55), all cores."""
+def cpu_baseline(arch, size, budget_s, sd=None, images=None):
+    """CPU oracle forward, batch 1 (the reference's default path, test_dir.py:52-55), all cores.
+    sd / images: time the forwards on THESE inputs and hand their descriptors back (second return value) -
+    the parity leg needs the oracle's output for the same images anyway, and the time of an fp32 forward
+    does not depend on the weight values."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import dir_oracle as O          # the only oracle import of this file: the timed CPU port
+    import dir_oracle as O          # the only oracle import of this file: the timed CPU port / the parity checker
     import synth
-    sd = synth.synth_state_dict(arch, seed=7)
+    if sd is None:
+        sd = synth.synth_state_dict(arch, seed=7)
     # thread count: the box may expose more logical CPUs than its cgroup lets run; pick the
     # fastest of a few counts on a probe at half the image side instead of trusting nproc
     allotted = cpu_allotted()
@@ -80,18 +84,109 @@ def cpu_baseline(arch, size, budget_s):
         if dt < best[0]:
             best = (dt, nt)
     torch.set_num_threads(best[1])
-    x = synth.synth_images(11, 1, size, size)
-    O.rmac_forward(sd, arch, x)   # warm-up (allocator, oneDNN primitive cache)
+    x = synth.synth_images(11, 1, size, size) if images is None else images
+    O.rmac_forward(sd, arch, x[:1])   # warm-up (allocator, oneDNN primitive cache)
+    outs = []
     n, t0 = 0, time.perf_counter()
     while True:
-        O.rmac_forward(sd, arch, x)
+        d = O.rmac_forward(sd, arch, x[n % len(x):n % len(x) + 1])
+        if n < len(x):
+            outs.append(d.reshape(1, -1))
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 64:
+        if (el >= budget_s and n >= len(x)) or n >= 64:
             break
-    return {'value': round(n / el, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
-            'cpu_allotted': allotted, 'cpu_visible': visible, 'kind': 'port',
-            'sample': '%d x %s fp32 %dx%d forward, batch 1, oracle/dir_oracle.py (%.1f s)' % (n, arch, size, size, el)}
+    return ({'value': round(n / el, 4), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
+             'cpu_allotted': allotted, 'cpu_visible': visible, 'kind': 'port',
+             'sample': '%d x %s fp32 %dx%d forward, batch 1, oracle/dir_oracle.py (%.1f s)' % (n, arch, size, size, el)},
+            torch.cat(outs).numpy())
+
+
+def precision_leg(arch, size, batch, x_bench, cpu_seconds):
+    """Outside the timed region, rank 0 at N = 1: what the three storage formats cost and what they lose.
+
+      images_per_sec   the same step as the headline in fp16 (the host mirror's default) and in the strict fp32
+                       mode (conv_f32.hip), a few steps each
+      one_minus_cos    engine vs the fp32 CPU oracle (oracle/dir_oracle.py) on the BatchNorm-calibrated synthetic
+                       checkpoint - the conditioned network on which 16-bit storage is visible - for two images at
+                       the bench size travelling INSIDE a batch of `batch` (so the timed kernel mix computes them)
+      map              |mAP(engine) - mAP(oracle)| through extraction -> PCA whitening -> similarity -> revisitop AP
+                       (the ROxford protocol: easy / hard / junk lists) on a small synthetic retrieval set
+
+    Returns (dict for config['precision'], the cpu_baseline dict) - the CPU forwards that produce the parity
+    reference are the timed cpu_baseline sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import dir_oracle as O
+    import synth
+    from dirtorch_amd import nets
+    from dirtorch_amd.utils import common
+
+    def engine(sd, dtype):
+        net = nets.create_model(arch + '_rmac', pretrained='')
+        net.load_state_dict(sd)
+        net.compute_dtype = dtype
+        return net.cuda().eval()
+
+    out = {'images_per_sec': {}, 'one_minus_cos': {}, 'map': {}}
+    # ---- throughput of the other two formats on the headline workload ------------------------------------
+    sd0 = synth.synth_state_dict(arch, seed=7)
+    for dtype, b, steps in (('fp16', batch, 8), ('f32', max(1, batch // 4), 2)):
+        net = engine(sd0, dtype)
+        xb = x_bench[:b]
+        net(xb)
+        net(xb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(xb)
+        torch.cuda.synchronize()
+        out['images_per_sec'][dtype] = round(b * steps / (time.perf_counter() - t0), 1)
+        out['images_per_sec'][dtype + '_batch'] = b
+        del net
+        torch.cuda.empty_cache()
+    # ---- descriptors vs the CPU oracle at the bench size, calibrated checkpoint --------------------------
+    sd = synth.calibrated_state_dict(arch, synth.synth_images(99, 2, size, size), seed=7)
+    xp = synth.synth_images(4, 2, size, size)
+    cpu, ref = cpu_baseline(arch, size, cpu_seconds, sd=sd, images=xp)
+    xin = x_bench.clone()
+    xin[:2] = xp.cuda()
+    for dtype in ('bf16', 'fp16', 'f32'):
+        net = engine(sd, dtype)
+        b = batch if dtype != 'f32' else max(2, batch // 4)
+        got = net(xin[:b])[:2].cpu().numpy()
+        out['one_minus_cos'][dtype] = float('%.3g' % (1 - O.cosine(got, ref)).max())
+        del net
+        torch.cuda.empty_cache()
+    out['one_minus_cos']['checkpoint'] = 'BatchNorm-calibrated synthetic (tests/synth.py), 2 images inside the batch'
+    # ---- mAP through the whole post-extraction path ----------------------------------------------------------
+    r = np.random.RandomState(11)
+    N, Q, S = 200, 20, 96
+    imgs = synth.synth_images(21, N, S, S).numpy()
+    gnd = []
+    for q in range(Q):
+        idx = r.choice(np.arange(Q, N), 9, replace=False)
+        for j, sigma in zip(idx[:6], (0.05, 0.1, 0.15, 0.3, 0.45, 0.6)):
+            imgs[j] = imgs[q] + sigma * r.standard_normal(imgs[q].shape).astype(np.float32)
+        gnd.append({'easy': sorted(idx[:3].tolist()), 'hard': sorted(idx[3:6].tolist()), 'junk': sorted([q] + idx[6:].tolist())})
+    xs = torch.from_numpy(imgs)
+    sdm = synth.calibrated_state_dict(arch, synth.synth_images(99, 16, S, S), seed=7)
+    refd = torch.cat([O.rmac_forward(sdm, arch, xs[i:i + 50]).reshape(-1, 2048) for i in range(0, N, 50)]).numpy()
+    P = O.fit_pca(refd[Q:])
+    kw = dict(whitenp=0.25, whitenv=32)
+    ref_w = O.whiten_features(refd, P, **kw)
+    m_ref = O.mean_ap(O.matmul(ref_w[:Q], ref_w), gnd)
+    out['map']['set'] = ('%d synthetic %dx%d images, %d queries with planted near-duplicates, revisitop easy/hard/junk '
+                         'protocol, PCA whitening to 32-d (calibrated checkpoint)' % (N, S, S, Q))
+    out['map']['oracle'] = {k: round(v, 5) for k, v in m_ref.items()}
+    for dtype in ('bf16', 'fp16', 'f32'):
+        net = engine(sdm, dtype)
+        got = torch.cat([net(xs[i:i + 50].cuda()) for i in range(0, N, 50)]).cpu().numpy()
+        got_w = common.whiten_features(got, P, **kw)
+        m = O.mean_ap(common.matmul(got_w[:Q], got_w), gnd)
+        out['map']['d_map_' + dtype] = float('%.3g' % max(abs(m[k] - m_ref[k]) for k in m_ref))
+        del net
+        torch.cuda.empty_cache()
+    return out, cpu
 
 
 def layer_group(name):
@@ -140,6 +235,148 @@ def kernel_table(prof, nprof, peak_tf, traffic):
                      'pmc_traffic_ratio'], 'rows': rows}
 
 
+def bench_distractors(args, world, rank, dist):
+    """BASELINE configs[3]: RParis6K + 1M distractors.  Rank r owns the contiguous row range
+    shard_range(N, r, W) of the [N, 2048] fp32 database (generated on the device: unit-norm rows), the Q query
+    descriptors are replicated.  A step is the post-extraction path of dirtorch/test_dir.py:145-167 over the whole
+    database:
+
+      --exchange descriptors  (north_star) ONE all_gather_into_tensor of the padded [ceil(N/W), 2048] blocks
+                              (8.24 GB at N = 1 006 322), then on every rank: Q x N similarity (sim_split.hip) ->
+                              device rank counts + revisitop AP (ranking.hip)
+      --exchange scores       every rank scores only ITS rows (Q x N/W), ONE all-gather of the [Q, ceil(N/W)]
+                              score blocks (N*Q*4 B = 0.28 GB), then rank + AP: the same APs bit for bit with
+                              29x fewer bytes on xGMI and 1/W of the similarity per GPU
+
+    value = database rows ranked per second, whole job (N * steps / time); scaling 'strong' (N is fixed)."""
+    from dirtorch_amd import distributed as ddist
+    from dirtorch_amd import ops, ranking
+    N, Q, D, K, Wm = args.db_rows, args.queries, 2048, args.steps, args.warmup
+    lo, hi = ddist.shard_range(N, rank, world)
+    rows = max(h - l for l, h in (ddist.shard_range(N, r, world) for r in range(world)))
+    g = torch.Generator(device='cuda').manual_seed(77 + rank)
+    local = torch.zeros(rows, D, device='cuda')                      # padded to the common block size
+    for i in range(0, hi - lo, 65536):                               # (chunked: no second 8 GB temporary)
+        n = min(65536, hi - lo - i)
+        local[i:i + n] = torch.nn.functional.normalize(torch.randn(n, D, generator=g, device='cuda'), dim=1)
+    gq = torch.Generator(device='cuda').manual_seed(5)
+    qs = torch.nn.functional.normalize(torch.randn(Q, D, generator=gq, device='cuda'), dim=1)
+
+    class _DB(object):   # revisitop-format relevance lists (easy / hard / junk), same on every rank
+        relevants = None
+    r = np.random.RandomState(1)
+    db = _DB()
+    db.nimg, db.nquery, db.easy, db.hard, db.junk = N, Q, [], [], []
+    for q in range(Q):
+        idx = r.choice(N, 200, replace=False)
+        db.easy.append(sorted(idx[:80].tolist()))
+        db.hard.append(sorted(idx[80:160].tolist()))
+        db.junk.append(sorted(idx[160:].tolist()))
+    tables = ranking.build_probe_tables(db)
+    sizes = [ddist.shard_range(N, r_, world) for r_ in range(world)]
+    full = torch.empty(world * rows, D, device='cuda') if args.exchange == 'descriptors' and world > 1 else None
+    sc_all = torch.empty(world, Q, rows, device='cuda') if args.exchange == 'scores' and world > 1 else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t_x, t_s, t_r = [], [], []
+
+    def step(record):
+        if record:
+            ev[0].record()
+        if args.exchange == 'descriptors':
+            if world > 1:
+                dist.all_gather_into_tensor(full, local)              # the one exchange step (RCCL over xGMI)
+            if record:
+                ev[1].record()
+            if world > 1 and rows * world != N:
+                # shards of unequal length arrive padded: score block by block instead of compacting 8 GB
+                scores = torch.cat([ops.similarity(qs, full[r_ * rows:r_ * rows + (h - l)])
+                                    for r_, (l, h) in enumerate(sizes)], dim=1)
+            else:
+                scores = ops.similarity(qs, full if world > 1 else local[:N])
+        else:
+            mine = ops.similarity(qs, local)                          # [Q, rows] (padding rows score 0)
+            if record:
+                ev[1].record()
+            if world > 1:
+                dist.all_gather_into_tensor(sc_all, mine)
+                scores = torch.cat([sc_all[r_, :, :h - l] for r_, (l, h) in enumerate(sizes)], dim=1).contiguous()
+            else:
+                scores = mine[:, :N].contiguous()
+        if record:
+            ev[2].record()
+        aps = ranking.eval_aps_device(db, scores, tables)
+        if record:
+            ev[3].record()
+            torch.cuda.synchronize()
+            a, b, c = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+            # descriptors: exchange, then similarity; scores: similarity, then exchange
+            (t_x if args.exchange == 'descriptors' else t_s).append(a)
+            (t_s if args.exchange == 'descriptors' else t_x).append(b)
+            t_r.append(c)
+        return aps
+
+    for _ in range(max(Wm, 1)):
+        aps = step(False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        aps = step(False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    for _ in range(3):      # per-phase durations (events on torch's current stream, where every kernel above runs)
+        step(True)
+    if rank != 0:
+        return
+    mean = lambda v: sum(v) / len(v) if v else 0.0   # noqa: E731
+    sim_ms, x_ms, r_ms = mean(t_s), mean(t_x), mean(t_r)
+    sim_rows = N if args.exchange == 'descriptors' else rows
+    sim_bytes = sim_rows * D * 4 + Q * sim_rows * 4          # database rows once + the score block (SURVEY 8d)
+    x_bytes = ((world - 1) * rows * D * 4) if args.exchange == 'descriptors' else ((world - 1) * Q * rows * 4)
+    out = {
+        'metric': 'database descriptors ranked/sec (Q x N similarity + revisitop AP, %d x %d x %d)' % (Q, N, D),
+        'value': round(N * K / el, 1), 'unit': 'db_rows/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+        'ms_per_step': round(el / K * 1e3, 3), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[3]: RParis6K + 1M synthetic distractors (N = %d unit-norm 2048-d rows, Q = %d), '
+                               'database sharded over the ranks, one all-gather of %s, similarity + device rank/AP'
+                               % (N, Q, 'descriptor blocks' if args.exchange == 'descriptors' else 'score blocks'),
+                   'exchange': args.exchange, 'rows_per_rank': rows, 'mAP_medium': round(float(np.mean([a['medium'] for a in aps])), 6)},
+        'roofline': {'bound': 'hbm', 'kernel': 'sim_split_kernel' if sim_rows >= 32768 else 'gemm_nt_f32',
+                     'achieved': round(sim_bytes / (sim_ms * 1e-3) / 1e9, 1) if sim_ms else None, 'peak': PEAK_HBM_GBS,
+                     'unit': 'GB/s', 'frac': round(sim_bytes / (sim_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sim_ms else None,
+                     'traffic': None, 'avg_launch_ms': round(sim_ms, 4), 'algorithmic_bytes_per_launch': sim_bytes,
+                     'rank_ap_ms': round(r_ms, 4),
+                     'exchange': {'bound': 'xgmi', 'bytes_received_per_rank': x_bytes, 'ms': round(x_ms, 4),
+                                  'achieved': round(x_bytes / (x_ms * 1e-3) / 1e9, 1) if (x_ms and world > 1) else None,
+                                  'peak': 7 * 153.0, 'unit': 'GB/s',
+                                  'note': '7 xGMI links x ~153 GB/s per GPU; a ring all-gather is bound by ONE link'}},
+        'cpu_baseline': None,
+    }
+    if world == 1 and args.cpu_seconds > 0:
+        # the reference's CPU form of the same step (common.matmul -> np.dot, generic.py:207 argsort per query and
+        # mode) on a bounded sample: 50k database rows, all queries
+        n = min(N, 50000)
+        a, b = qs.cpu().numpy(), local[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        sc = np.dot(a, b.T)
+        for q in range(Q):
+            for _ in range(3):
+                np.argsort(sc[q])[::-1]
+        dt = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': round(n / dt, 1), 'unit': 'db_rows/sec', 'cores': torch.get_num_threads(),
+                               'kind': 'port', 'sample': 'np.dot(Q x D, D x %d) + 3 argsorts per query (%.2f s)' % (n, dt)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -153,7 +390,17 @@ def main():
                     help='time every admissible tile variant per layer first (default: the built-in tile heuristic, '
                          'which the tuner no longer beats at this shape)')
     ap.add_argument('--no-autotune', action='store_true', help='(default; kept for old command lines)')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU legs (baseline + precision)')
+    ap.add_argument('--no-precision', action='store_true',
+                    help='skip the fp16 / strict-fp32 throughput and the parity-vs-oracle fields (config.precision)')
+    ap.add_argument('--workload', default='extract', choices=['extract', 'distractors'],
+                    help="extract = BASELINE configs[1] (default); distractors = configs[3]: a database of --db-rows "
+                         "2048-d descriptors sharded over the ranks, ONE all-gather, Q x N similarity, device rank + AP")
+    ap.add_argument('--db-rows', type=int, default=1006322, help='distractors: database size (RParis6K + 1M)')
+    ap.add_argument('--queries', type=int, default=70)
+    ap.add_argument('--exchange', default='descriptors', choices=['descriptors', 'scores'],
+                    help="distractors: what crosses xGMI - the [N/W, 2048] descriptor blocks (north_star) or, the "
+                         "cheaper layout, each rank's [Q, N/W] score block")
     ap.add_argument('--profile-every', type=int, default=4,
                     help='record per-launch HIP events on every n-th timed step (1 = all steps)')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer profile to stderr')
@@ -175,6 +422,13 @@ def main():
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run the RCCL path runs even at N = 1
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
+
+    if args.workload == 'distractors':
+        bench_distractors(args, world, rank, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import synth
     from dirtorch_amd import nets
@@ -295,9 +549,15 @@ def main():
                 ms /= n
                 print('%-24s %-36s %8.3f ms %8.1f TF/s %8.1f GB/s' % (
                     name, kern, ms, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
-        cpu = None
+        cpu, precision = None, None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(args.arch, S, args.cpu_seconds)
+            del shard
+            net._ws = None
+            torch.cuda.empty_cache()
+            if args.no_precision:
+                cpu, _ = cpu_baseline(args.arch, S, args.cpu_seconds)
+            else:
+                precision, cpu = precision_leg(args.arch, S, B, x, args.cpu_seconds)
         value = world * B * K / el
         out = {
             'metric': 'images/sec descriptor extraction (%s-GeM, %dx%d)' % (args.arch, S, S),
@@ -309,7 +569,10 @@ def main():
                        'batch_per_gpu': B, 'global_batch': world * B, 'input': 'fp32 NCHW resident in HBM',
                        'gflop_per_image': GFLOP_PER_IMG.get((args.arch, S)),
                        'tflops_per_gpu': round(value / world * GFLOP_PER_IMG.get((args.arch, S), 0) / 1e3, 1),
-                       'parallelism': 'image-parallel shards, 1 all-gather of descriptors' if world > 1 else 'single GPU'},
+                       'parallelism': 'image-parallel shards, 1 all-gather of descriptors' if world > 1 else 'single GPU',
+                       # the other storage formats on the same step, and what each loses against the fp32 CPU
+                       # oracle (descriptors at the bench size + mAP through whitening / similarity / AP)
+                       'precision': precision},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

@@ -38,6 +38,9 @@ def short(name):
                                                           '/splitk' if sk == 'true' else '',
                                                           '/dual' if dual == 'true' else '',
                                                           '/stem' if c16 == 'true' else '', dt.lower())
+    m = re.search(r'conv_f32_kernel<(\d+)>', name)
+    if m:   # the strict fp32 path (csrc/conv_f32.hip)
+        return 'conv_f32<128x%s>' % m.group(1)
     m = re.search(r'conv_c3c1_kernel<dir::(\w+), (\d+), (\w+), (\d+)>', name)
     if m:
         return 'conv_c3c1<%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '', m.group(1).lower())
@@ -118,7 +121,7 @@ def pmc(fd, wd, out, traffic=None):
 
 
 # ---- per-kernel roofline table ---------------------------------------------------------------------
-ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
+ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'conv_f32<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
 PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
 FOLLOW_UP = ('gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel')
 MEASURED_TF, MEASURED_GBS = 1582.0, 6305.0   # scripts/probes/*_ceiling.hip on a pool box (profiles/r02_*_ceiling.txt)
@@ -130,7 +133,9 @@ def bench_kernel_name(k):
     return {'stem_pool_kernel': 'stem_pool', 'stem_pool_persist_kernel': 'stem_pool', 'prep_input_kernel': 'prep_input',
             'global_pool_kernel': 'global_pool',
             'gemm_nt_small_kernel': 'gemm_nt_f32', 'gemm_nt_f32_kernel': 'gemm_nt_f32',
-            'maxpool_kernel': 'maxpool_3x3s2', 'upsample_add_kernel': 'upsample_add'}.get(k, k)
+            'maxpool_kernel': 'maxpool_3x3s2', 'upsample_add_kernel': 'upsample_add',
+            'prep_input_f32_kernel': 'prep_input_f32', 'maxpool_f32_kernel': 'maxpool_f32',
+            'global_pool_f32_kernel': 'global_pool_f32', 'upsample_add_f32_kernel': 'upsample_add_f32'}.get(k, k)
 
 
 def layer_group(name):

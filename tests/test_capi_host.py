@@ -174,7 +174,8 @@ def test_profile_tooling_knows_every_engine_kernel():
     names = sorted({re.sub(r'\(.*$', '', l).replace('__device_stub__', '').replace('void ', '') for l in raw})
     assert len(names) > 100, names[:5]
     variants = set(ops.conv_variant_names())
-    forward = {'stem_pool', 'prep_input', 'global_pool', 'gemm_nt_f32', 'maxpool_3x3s2', 'upsample_add'}
+    forward = {'stem_pool', 'prep_input', 'global_pool', 'gemm_nt_f32', 'maxpool_3x3s2', 'upsample_add',
+               'prep_input_f32', 'maxpool_f32', 'global_pool_f32', 'upsample_add_f32'}      # + the strict path's
     other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_counts_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
              'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'split_queries_kernel', 'fill_noise_kernel',
              'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel'}
@@ -182,6 +183,7 @@ def test_profile_tooling_knows_every_engine_kernel():
         k = S.bench_kernel_name(S.short(n))
         if 'conv' in n and 'finalize' not in n and 'naive' not in n:
             m = re.match(r'^conv_igemm<([^>/]+)(/splitk|/dual)?>$', k)
-            assert (m and m.group(1) in variants) or re.match(r'^conv_c3c1<(64|128)(,ds)?>$', k), (n, k)
+            assert (m and m.group(1) in variants) or re.match(r'^conv_c3c1<(64|128)(,ds)?>$', k) or \
+                re.match(r'^conv_f32<128x(64|128)>$', k), (n, k)
         else:
             assert k in forward or k in other, (n, k)
