@@ -495,11 +495,18 @@ def main():
         hbm_bound = (dfl / dby) < (peak_tf * 1e12) / (PEAK_HBM_GBS * 1e9)
         traffic_all = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')   # PMC-derived HBM bytes / launch (scripts/summarize_prof.py)
+        traffic_note = 'no profiles/traffic.json'
         if os.path.isfile(tfile):
             try:
                 traffic_all = json.load(open(tfile))
+                sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+                import summarize_prof
+                built, now = traffic_all.pop('_build', None), summarize_prof.csrc_hash()
+                traffic_note = 'PMC pass (2 x FETCH_SIZE + WRITE_SIZE) of build %s' % built
+                if built != now:        # PMC bytes of other kernel sources are not a measurement of this library
+                    traffic_all, traffic_note = None, 'stale: profiles/traffic.json is from build %s, this is %s' % (built, now)
             except Exception:
-                traffic_all = None
+                traffic_all, traffic_note = None, 'profiles/traffic.json unreadable'
         traffic = (traffic_all or {}).get(dom)
         if isinstance(traffic, dict):        # per-shape entries: average over the kernel's launch mix of this step
             per = {}
@@ -515,7 +522,7 @@ def main():
                 'peak': PEAK_HBM_GBS if hbm_bound else peak_tf,
                 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                 'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / peak_tf, 4),
-                'traffic': traffic,
+                'traffic': traffic, 'traffic_source': traffic_note,
                 'note': 'frac = the largest-time-share kernel against ITS roof; whole step = step_mfma_frac of the MFMA peak',
                 # measured once on a pool box (profiles/r02_mfma_ceiling.txt): bare register-only MFMA loop, 8 waves/CU
                 'mfma_ceiling_measured_tflops': {'random_operands': 1582, 'zero_operands': 2285},

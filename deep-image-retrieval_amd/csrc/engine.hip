@@ -670,8 +670,11 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         // so the seam kernel also serves layer1 -> layer2; run_seam checks the widths it can hold)
         const bool seam_next = desc.bottleneck && bi + 1 < blocks.size() && !tuning;
         bool ds_in_seam = false;
+        // (the DS form also needs the NEXT block's conv1 to be 64 wide - conv_c3c1_admissible: Cout2 == Cin; a
+        // layer1 of a single block is followed by layer2's 128-wide conv1 and takes the two-source GEMM instead)
         if (bd.down >= 0 && seam_next && convs[bd.conv3].d_w_ds && convs[bd.conv3].Cin == 64 &&
-            convs[bd.down].Cin == 64 && convs[bd.down].stride == 1) {
+            convs[bd.down].Cin == 64 && convs[bd.down].stride == 1 && convs[blocks[bi + 1].conv1].Cout == 64 &&
+            convs[blocks[bi + 1].conv1].Cin == convs[bd.conv3].Cout) {
             // (oversized batches are left to conv_launch's own 2^31-byte error)
             ds_in_seam = !sw.c3c1_off && !sw.no_ds_seam && (sw.c3c1_force || ((long)B * oh * ow + 63) / 64 >= kSeamMinTiles) &&
                          (long)B * oh * ow * convs[bd.conv3].Cout < (1L << 30);

@@ -84,7 +84,10 @@ int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx
 // expanded against itself (test_dir.py:33-34).  One workgroup per row: k selection rounds over the
 // row (each finds the best item ranking after the previous pick - value descending, index descending
 // on ties, the order of np.argsort(...)[::-1]; the reference's np.argpartition leaves the choice among
-// tied boundary values unspecified), then the weighted sum and the L2 norm.
+// tied boundary values unspecified), then the weighted sum and the L2 norm.  Picks are buffered 256 at a time
+// (any k <= m, like the reference); the running sum lives in the output row between batches.  A row with
+// non-finite similarities (a NaN descriptor from --load-feats, say) can run out of selectable items: the pick is
+// then (row 0, weight NaN) and the output row is NaN, which is what the reference's arithmetic propagates.
 constexpr int kMaxExpandK = 256;
 
 __global__ void __launch_bounds__(256) expand_rows_kernel(const float* __restrict__ descs,
@@ -107,6 +110,7 @@ __global__ void __launch_bounds__(256) expand_rows_kernel(const float* __restric
     int pj = 0x7fffffff;
     const int ialpha = (int)alpha;
     const bool int_alpha = (float)ialpha == alpha && ialpha >= 0 && ialpha <= 64;
+    for (int d = tid; d < D; d += 256) out[(size_t)i * D + d] = descs[(size_t)i * D + d];
     for (int round = 0; round < k; ++round) {
         float bv = -INFINITY;
         int bj = -1;
@@ -142,18 +146,25 @@ __global__ void __launch_bounds__(256) expand_rows_kernel(const float* __restric
             } else {
                 w = powf(pv, alpha);
             }
-            s_pick_w[round] = w;
-            s_pick_j[round] = pj;
+            s_pick_w[round % kMaxExpandK] = pj < 0 ? NAN : w;
+            s_pick_j[round % kMaxExpandK] = pj < 0 ? 0 : pj;
         }
         __syncthreads();
+        const int filled = round % kMaxExpandK + 1;
+        if (filled == kMaxExpandK || round == k - 1) {   // flush this batch of picks into the running sum
+            for (int d = tid; d < D; d += 256) {
+                float acc = out[(size_t)i * D + d];
+                for (int t = 0; t < filled; ++t) acc += db[(size_t)s_pick_j[t] * D + d] * s_pick_w[t];
+                out[(size_t)i * D + d] = acc;
+            }
+            __syncthreads();
+        }
     }
     // weighted mean over the k + 1 rows, then the L2 norm (test_dir.py:38-42)
     const float inv = 1.f / (float)(k + 1);
     float ss = 0.f;
     for (int d = tid; d < D; d += 256) {
-        float acc = descs[(size_t)i * D + d];
-        for (int t = 0; t < k; ++t) acc += db[(size_t)s_pick_j[t] * D + d] * s_pick_w[t];
-        acc *= inv;
+        const float acc = out[(size_t)i * D + d] * inv;
         out[(size_t)i * D + d] = acc;
         ss += acc * acc;
     }
@@ -172,7 +183,6 @@ int expand_descriptors(const float* descs, int n, const float* db, int m, int D,
     if (n <= 0) return DIR_OK;
     if (k < 0 || alpha < 0.f) return fail(DIR_ERR_INVALID, "expand_descriptors: k and alpha must be non-negative");
     if (k > m) return fail(DIR_ERR_INVALID, "expand_descriptors: k exceeds the number of candidate rows");
-    if (k > kMaxExpandK) return fail(DIR_ERR_INVALID, "expand_descriptors: k > 256 is not supported");
     if (self_set && m != n) return fail(DIR_ERR_INVALID, "expand_descriptors: self expansion needs db == descs");
     const size_t rows_fit = sim_bytes / ((size_t)m * sizeof(float));
     if (rows_fit == 0) return fail(DIR_ERR_WORKSPACE, "expand_descriptors: scratch smaller than one score row");

@@ -307,7 +307,8 @@ int dir_revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, cons
  * rows j of db most similar to descs[i])), sim = descs . db^T in fp32; self_set != 0 (db == descs,
  * m == n): a row is not its own neighbour (its self-similarity counts as 0, test_dir.py:33-34).
  * descs [n][D], db [m][D], out [n][D] fp32 contiguous; sim: caller's scratch of sim_bytes >= 4*m
- * (rows are processed in chunks of sim_bytes / (4*m)); 0 <= k <= min(m, 256), alpha >= 0. */
+ * (rows are processed in chunks of sim_bytes / (4*m)); 0 <= k <= m, alpha >= 0.  A row whose similarities are
+ * not finite yields a NaN row (the reference propagates NaN the same way). */
 int dir_expand_descriptors(const float* descs, int n, const float* db, int m, int D, int k, float alpha,
                            int self_set, float* out, float* sim, size_t sim_bytes, void* stream);
 

@@ -29,6 +29,23 @@ import sys
 from collections import defaultdict
 
 
+def csrc_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/dir_engine.h): profiles/traffic.json carries it as
+    '_build', and bench.py drops `roofline.traffic` when the library it runs was built from other sources - PMC
+    bytes of an older kernel are not a measurement of this one."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, 'deep-image-retrieval_amd', 'csrc', '*.hip')) +
+                   glob.glob(os.path.join(root, 'deep-image-retrieval_amd', 'csrc', '*.h')) +
+                   [os.path.join(root, 'include', 'dir_engine.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def short(name):
     m = re.search(r'conv_igemm_kernel<dir::(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\w+))?>', name)
     if m:   # <DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK[, DUAL]> -> the variant names of csrc/conv_igemm.hip
@@ -246,6 +263,8 @@ def table(launches, stats_d, sq_d, fetch_d, write_d, out, traffic=None):
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
     if traffic:
+        tr = dict(tr)
+        tr['_build'] = csrc_hash()
         json.dump(tr, open(traffic, 'w'), indent=1)
 
 

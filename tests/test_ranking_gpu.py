@@ -176,6 +176,20 @@ def test_expand_descriptors_at_dataset_scale_and_errors():
                                      scratch_bytes=37 * 600 * 4).cpu().numpy()      # 37 rows per pass
     # another GEMM tiling of the same products (fp32 summation order): equal to rounding, not bit for bit
     np.testing.assert_allclose(chunked, got_s, rtol=0, atol=1e-6)
+    # k beyond one pick buffer (256): the reference accepts any k <= m (np.argpartition, test_dir.py:36)
+    ref_k = O.expand_descriptors(q[:8], db=db[:900], alpha=1, k=300)
+    got_k = td.expand_descriptors(q[:8], db=db[:900], alpha=1, k=300)
+    assert np.all(1 - O.cosine(got_k, ref_k) < 1e-6)
+    all_k = td.expand_descriptors(q[:3], db=db[:520], alpha=0, k=520)    # k == m: the plain mean of everything
+    want = (q[:3] + db[:520].sum(0)) / 521
+    assert np.all(1 - O.cosine(all_k, want / np.linalg.norm(want, axis=1, keepdims=True)) < 1e-6)
+    # a NaN descriptor (e.g. from --load-feats) propagates as a NaN row, as in the reference's arithmetic; the
+    # other rows are untouched and nothing reads out of bounds
+    bad = q[:4].copy()
+    bad[1, 7] = np.nan
+    got_bad = td.expand_descriptors(bad, db=db[:100], alpha=1, k=5)
+    assert np.isnan(got_bad[1]).all() and np.isfinite(got_bad[[0, 2, 3]]).all()
+    assert np.all(1 - O.cosine(got_bad[[0, 2, 3]], O.expand_descriptors(q[:4], db=db[:100], alpha=1, k=5)[[0, 2, 3]]) < 1e-6)
     with pytest.raises(ValueError):
         td.expand_descriptors(q[:5], db=db[:3], alpha=1, k=4)            # k > candidates, as np.argpartition
     with pytest.raises(AssertionError):
