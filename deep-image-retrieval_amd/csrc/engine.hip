@@ -197,7 +197,14 @@ int dir_engine::finalize(int dt) {
             continue;
         }
         std::vector<uint16_t> packed16(packed.size());
-        for (size_t i = 0; i < packed.size(); ++i) packed16[i] = to16(packed[i]);
+        for (size_t i = 0; i < packed.size(); ++i) {
+            packed16[i] = to16(packed[i]);
+            // fp16 saturates at 65504: a folded weight beyond that would become inf here, on the host, where no
+            // kernel's overflow word can see it (and inf * 0 = NaN is then flushed to 0 by the next fused ReLU)
+            if (dt == DIR_FP16 && (packed16[i] & 0x7c00u) == 0x7c00u && std::isfinite(packed[i]))
+                return fail(DIR_ERR_RANGE, "finalize: a BatchNorm-folded weight of " + L.name + " (" +
+                                               std::to_string(packed[i]) + ") exceeds the fp16 range; use DIR_BF16 or DIR_F32");
+        }
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed16.size() * 2));
         DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
         L.h_w.swap(packed16);

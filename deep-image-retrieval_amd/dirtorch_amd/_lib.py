@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIRTORCH_AMD_LIB') or os.path.join(_HERE, 'libdir_engine.so')
 
 DIR_BF16, DIR_FP16, DIR_F32 = 0, 1, 2
+DIR_ERR_RANGE = -7      # dir_status: a finite fp32 weight does not fit the chosen 16-bit format
 DTYPES = {'bf16': DIR_BF16, 'fp16': DIR_FP16, 'f32': DIR_F32}
 DIR_IMG_F32_NCHW, DIR_IMG_U8_NHWC = 0, 1
 DIR_POOL_GEM, DIR_POOL_MAX, DIR_POOL_AVG = 0, 1, 2

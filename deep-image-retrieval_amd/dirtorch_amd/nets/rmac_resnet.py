@@ -215,7 +215,12 @@ class ResNet_RMAC(object):
                  shape, t.dim())
         if self.compute_dtype not in _lib.DTYPES:
             raise ValueError("compute_dtype must be 'bf16', 'fp16' or 'f32', not %r" % (self.compute_dtype,))
-        call('dir_engine_finalize', self._engine, _lib.DTYPES[self.compute_dtype])
+        try:
+            call('dir_engine_finalize', self._engine, _lib.DTYPES[self.compute_dtype])
+        except _lib.DirError as e:
+            if e.code == _lib.DIR_ERR_RANGE:     # same exception the extraction loops raise for an fp16 overflow
+                raise FloatingPointError('%s; run with DIRTORCH_AMD_DTYPE=bf16 or DIRTORCH_AMD_DTYPE=f32' % e)
+            raise
         self._built_dtype = self.compute_dtype
         self._dirty = False
         self._tuned = set()

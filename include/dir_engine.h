@@ -36,7 +36,8 @@ typedef enum dir_status {
     DIR_ERR_MISSING = -3,     /* a state-dict tensor was never supplied              */
     DIR_ERR_WORKSPACE = -4,   /* workspace too small                                 */
     DIR_ERR_HIP = -5,         /* a HIP runtime call failed                           */
-    DIR_ERR_NOMEM = -6
+    DIR_ERR_NOMEM = -6,
+    DIR_ERR_RANGE = -7        /* a finite fp32 weight does not fit the chosen 16-bit format  */
 } dir_status;
 
 /* Storage format of activations and weights, chosen at dir_engine_finalize (the C ABI has no default; the Python

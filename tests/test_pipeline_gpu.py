@@ -402,7 +402,7 @@ def test_fp16_overflow_is_reported_not_returned(tmp_path):
 
 
 def test_fp16_overflow_hidden_by_a_later_relu_is_still_reported(tmp_path):
-    """An overflow planted in layer2: a huge bn1 gain makes conv1's post-ReLU output +inf in fp16, conv2 then
+    """An overflow planted in layer2: a huge bn1 shift makes conv1's post-ReLU output +inf in fp16, conv2 then
     sums inf - inf = NaN, and its fused ReLU - a hardware max, which returns the non-NaN operand - flushes
     the NaNs to 0: the descriptors come out FINITE and wrong.  The engine's overflow word (every kernel that
     stores an fp16 inf / NaN sets it, dir_engine_overflow) must still turn that into an error; bf16 (fp32's
@@ -416,9 +416,9 @@ def test_fp16_overflow_hidden_by_a_later_relu_is_still_reported(tmp_path):
     (tmp_path / 'list.txt').write_text('\n'.join(names) + '\n')
     db = datasets.create('ImageList("%s", root="%s")' % (tmp_path / 'list.txt', tmp_path / 'imgs'))
     x = O.synth_images(5, 2, 96, 96).cuda()
-    for arch, key in (('resnet50', 'layer2.0.bn1.weight'), ('resnet18', 'layer2.0.bn1.weight')):
+    for arch, key in (('resnet50', 'layer2.0.bn1.bias'), ('resnet18', 'layer2.0.bn1.bias')):
         sd = O.synth_state_dict(arch, seed=7, gemp=3.0)
-        sd[key] = sd[key] * 1e6
+        sd[key] = sd[key] + 1e5          # (a shift, not a gain: the folded WEIGHTS stay in range, see the last check)
         for dtype in ('fp16', 'bf16'):
             net = nets.create_model(arch + '_rmac', pretrained='')
             net.load_state_dict(sd)
@@ -439,6 +439,19 @@ def test_fp16_overflow_hidden_by_a_later_relu_is_still_reported(tmp_path):
             assert 'DIRTORCH_AMD_DTYPE=bf16' in str(ei.value)
             if hidden:
                 assert 'fp16 overflow inside the trunk' in str(ei.value)
+    # weights that do not fit fp16 are refused when the engine is built (DIR_ERR_RANGE): an inf weight would be
+    # born on the host, where no kernel's overflow word can see it
+    sd = O.synth_state_dict('resnet50', seed=7, gemp=3.0)
+    sd['layer3.1.bn2.weight'] = sd['layer3.1.bn2.weight'] * 1e7
+    net = nets.create_model('resnet50_rmac', pretrained='')
+    net.load_state_dict(sd)
+    net.compute_dtype = 'fp16'
+    net.cuda().eval()
+    with pytest.raises(FloatingPointError) as ei:
+        net(x)
+    assert 'layer3.1.conv2' in str(ei.value) and 'DIRTORCH_AMD_DTYPE=bf16' in str(ei.value)
+    net.compute_dtype = 'bf16'
+    assert torch.isfinite(net(x)).all()
     # a healthy checkpoint never trips the word (fp16, every kernel family of a 1024^2 batch)
     sd = O.synth_state_dict('resnet50', seed=7)
     net = nets.create_model('resnet50_rmac', pretrained='')
