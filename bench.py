@@ -563,7 +563,7 @@ def main():
         cpu, precision = None, None
         if world == 1 and args.cpu_seconds > 0:
             del shard
-            net._ws = None
+            net._ws = {}
             torch.cuda.empty_cache()
             if args.no_precision:
                 cpu, _ = cpu_baseline(args.arch, S, args.cpu_seconds)

@@ -37,6 +37,8 @@ struct ConvArgs {
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)
+    int rev_m;                               // persistent 1x1: walk the pixel tiles from the LAST one (read what the
+                                             // producer wrote most recently first: it is still in the 256 MB Infinity Cache)
     int no_xcd_map;                          // persistent kernels: 1 = tiles follow blockIdx (A/B; default 0 = XCD-aware)
     int flat;                                // 1x1, stride 1, no padding: pixel m reads pixel m
     uint32_t div_ohw_mul, div_ohw_shr;       // exact n / (OH*OW) and n / OW for n < 2^31

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
     uint32_t xvoff[NA], wvoff[NB];
     // per-lane DMA offsets of a tile (1x1: one tap, padding-free; the row mask is folded in)
     auto tile_offsets = [&](int tile) {
-        const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+        const int tile_n = tile % a.tiles_n, tile_m = a.rev_m ? a.tiles_m - 1 - tile / a.tiles_n : tile / a.tiles_n;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = tile_m * BM + i * 64 + (tid >> 3);
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
     }
 
     for (;;) {
-        const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+        const int tile_n = tile % a.tiles_n, tile_m = a.rev_m ? a.tiles_m - 1 - tile / a.tiles_n : tile / a.tiles_n;
         const int m_epi = tile_m * BM + wm * TM * 32;
         const int n_wave = tile_n * BN + wn * TN * 32;
 

@@ -106,8 +106,10 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     const float* const bz = sbias + wave * BNW + ecol;
 
     // input tile t -> NX registers per lane (block i = channels 64 i ..; out-of-range rows read zeros)
+    // (rev_m: the walk visits the pixel tiles from the last one - see ConvArgs::rev_m)
+    auto phys = [&](int t) { return a.rev_m ? mt - 1 - t : t; };
     auto load_x = [&](int t, u32x4_t* xr) {
-        const int m = t * BM + spix;
+        const int m = phys(t) * BM + spix;
         const uint32_t base = m < a.M ? (uint32_t)((m * a.Cin + sslot * 8) * 2) : kOOBr;
 #pragma unroll
         for (int i = 0; i < NX; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, i * 128, 0);
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     auto load_res = [&](int t, int j, u32x4_t* r) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass)
-            r[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, row_off(t * BM + j * 32 + pass * 8 + erow), 0, 0);
+            r[pass] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, row_off(phys(t) * BM + j * 32 + pass * 8 + erow), 0, 0);
     };
 
     u32x4_t xr[NX];
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
         const bool more = tile + per < mt;
         const int next = more ? tile + per : tile;   // last step: a harmless repeat
         load_x(next, xr);                            // lands during this tile's MFMAs
-        const int m0 = tile * BM;
+        const int m0 = phys(tile) * BM;
         load_res(tile, 1, rres1);
 
         const char* xb = smem + cur * XBUF;

@@ -90,7 +90,7 @@ struct dir_engine {
     int run_conv_f32(dir::ConvLayer& L, const float* x, const float* res, float* y, int B, int H, int W, int OH, int OW,
                      hipStream_t stream);
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
-                 int H, int W, int OH, int OW, hipStream_t stream);
+                 int H, int W, int OH, int OW, hipStream_t stream, bool rev_m = false);
     // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes
     // do not qualify and nothing was launched
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
@@ -103,7 +103,7 @@ struct dir_engine {
     // A/B switches, read from the environment ONCE per forward() (tests toggle them between calls; a getenv
     // per block would cost tens of microseconds of a 1.5 ms batch-1 step)
     struct Switches {
-        bool c3c1_off = false, c3c1_force = false, no_ds_seam = false, no_dual = false;
+        bool c3c1_off = false, c3c1_force = false, no_ds_seam = false, no_dual = false, rev_conv1 = false, rev_conv3 = false;
     } sw;
     float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,

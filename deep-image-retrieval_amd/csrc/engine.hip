@@ -384,9 +384,10 @@ int dir_engine::prof_end(hipStream_t stream) {
 
 // ---- one convolution ----------------------------------------------------------------------------
 int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
-                         int H, int W, int OH, int OW, hipStream_t stream) {
+                         int H, int W, int OH, int OW, hipStream_t stream, bool rev_m) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    a.rev_m = rev_m ? 1 : 0;
     a.x = x;
     a.w = L.d_w;
     a.bias = L.d_bias;
@@ -603,6 +604,8 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         sw.c3c1_force = mode && mode[0] == 'f';
         sw.no_ds_seam = getenv("DIRTORCH_AMD_NO_DS_SEAM") != nullptr;
         sw.no_dual = getenv("DIRTORCH_AMD_NO_DUAL") != nullptr;
+        sw.rev_conv1 = getenv("DIRTORCH_AMD_REV_CONV1") != nullptr;
+        sw.rev_conv3 = getenv("DIRTORCH_AMD_REV_CONV3") != nullptr;
     }
     Plan p;
     int rc = plan(B, H, W, &p);
@@ -699,7 +702,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         }
         if (desc.bottleneck) {
             if (!t1_ready) {   // (the previous block's fused seam kernel may have produced t1 already)
-                rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream);
+                rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream, sw.rev_conv1);
                 if (rc != DIR_OK) return rc;
             }
             t1_ready = false;
@@ -721,7 +724,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             if (fused == 1) {
                 t1_ready = true;
             } else if (!fused) {
-                rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream);
+                rc = run_conv(convs[bd.conv3], t2, resid, nxt, B, oh, ow, oh, ow, stream, sw.rev_conv3);
                 if (rc != DIR_OK) return rc;
             }
         } else {

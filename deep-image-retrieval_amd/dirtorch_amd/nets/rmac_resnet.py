@@ -81,7 +81,7 @@ class ResNet_RMAC(object):
         self._state = self._init_state()
         self._engine = None
         self._dirty = True
-        self._ws = None
+        self._ws = {}                  # HIP stream -> workspace tensor (one forward in flight per stream)
         self._tuned = set()
         self.autotune = os.environ.get('DIRTORCH_AMD_AUTOTUNE', '0') == '1'
 
@@ -253,10 +253,17 @@ class ResNet_RMAC(object):
     def _workspace(self, B, H, W):
         need = ctypes.c_size_t()
         call('dir_workspace_bytes', self._engine, B, H, W, ctypes.byref(need))
-        if self._ws is None or self._ws.numel() < need.value:
-            self._ws = None
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device='cuda')
-        return self._ws
+        # one workspace per stream: forwards issued on different streams (the batch-1 extraction loop overlaps a
+        # few images that way - a single 1024^2 image cannot fill 256 CUs) must not share scratch; on one stream
+        # successive forwards are ordered, so they can
+        key = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need.value:
+            self._ws.pop(key, None)
+            del ws
+            ws = torch.empty(need.value, dtype=torch.uint8, device='cuda')
+            self._ws[key] = ws
+        return ws
 
     def _prepare(self, x):
         if self._engine is not None and getattr(self, '_built_norm', None) != self._norm_constants():

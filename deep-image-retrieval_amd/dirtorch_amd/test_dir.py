@@ -67,6 +67,39 @@ def _check_finite(feats, net):
     return feats
 
 
+class StreamPool(object):
+    """Round-robin HIP streams for forwards that cannot share a batch (the reference's real workload: batch 1 at
+    native resolution, test_dir.py:52-55).  One 1024^2 image gives layers 3 / 4 16-128 workgroups for 256 CUs;
+    forwards issued on a few streams overlap on the device (each stream has its own engine workspace,
+    nets/rmac_resnet.py _workspace).  DIRTORCH_AMD_STREAMS=n (default 3; 1 = everything on the current stream).
+    Results are identical: the same kernels run on the same data, only their interleaving changes."""
+
+    def __init__(self, n=None):
+        n = int(os.environ.get('DIRTORCH_AMD_STREAMS', '3')) if n is None else n
+        self.streams = [torch.cuda.Stream() for _ in range(n)] if n > 1 and torch.cuda.is_available() else []
+        self.i = 0
+
+    def run(self, fn, *inputs):
+        """fn() on the next stream of the pool; `inputs` are the tensors it reads (produced on the current stream)."""
+        if not self.streams:
+            return fn()
+        cur = torch.cuda.current_stream()
+        s = self.streams[self.i % len(self.streams)]
+        self.i += 1
+        s.wait_stream(cur)                      # the inputs are ready when this stream starts
+        for t in inputs:
+            t.record_stream(s)                  # ... and stay allocated until it is done with them
+        with torch.cuda.stream(s):
+            out = fn()
+        out.record_stream(cur)                  # consumed on the caller's stream after join()
+        return out
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)
+
+
 def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=False, flip=None,
                            desc="Extract feats...", iscuda=True, threads=8, batch_size=8):
     """One descriptor per image of `dataset`, as a [N, D] tensor on the network's device.
@@ -81,6 +114,7 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
         return _check_finite(_extract_bucketed(loader, len(dataset), net, batch_size, desc), net)
     feats, kept = [], []
     nbatches = (len(dataset) + bs - 1) // bs
+    pool_ = StreamPool(None if (bs == 1 and net.iscuda) else 1)
     with torch.no_grad():
         for (imgs,) in tqdm.tqdm(loader, desc, total=nbatches):
             if flip:
@@ -89,10 +123,11 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
                     if flip and flip.pop(0):
                         imgs[i] = imgs[i].flip(waxis)
             imgs = common.variables([imgs], net.iscuda)[0]
-            d = net(imgs)
+            d = pool_.run(lambda: net(imgs), imgs)
             feats.append(d.reshape(1, -1) if d.dim() == 1 else d)   # B == 1 comes back as [D]
             if ret_imgs:
                 kept.append(imgs.cpu() if ret_imgs == 'cpu' else imgs)
+    pool_.join()
     feats = _check_finite(torch.cat(feats, dim=0), net)
     if not ret_imgs:
         return feats
@@ -108,16 +143,24 @@ def _extract_bucketed(loader, n, net, batch_size, desc):
     out = None
     buckets = {}                                   # (H, W, dtype) -> ([indices], [image tensors])
     pending, cap = 0, 8 * batch_size               # bound the parked images
+    pool_ = StreamPool()                           # part-filled buckets of rare sizes overlap on the device
+    results = []                                   # (indices, descriptors), scattered after the streams joined
 
     def run(key):
-        nonlocal out, pending
+        nonlocal pending
         idx, imgs = buckets.pop(key)
-        d = net(torch.cat(imgs, dim=0))
-        d = d.reshape(len(idx), -1)
-        if out is None:
-            out = torch.empty(n, d.shape[1], dtype=d.dtype, device=d.device)
-        out[torch.tensor(idx, device=d.device)] = d
+        x = torch.cat(imgs, dim=0)
+        d = pool_.run(lambda: net(x).reshape(len(idx), -1), x)
+        results.append((idx, d))
         pending -= len(idx)
+
+    def scatter():
+        nonlocal out
+        pool_.join()
+        for idx, d in results:
+            if out is None:
+                out = torch.empty(n, d.shape[1], dtype=d.dtype, device=d.device)
+            out[torch.tensor(idx, device=d.device)] = d
 
     with torch.no_grad():
         for i, (img,) in enumerate(tqdm.tqdm(loader, desc, total=n)):
@@ -133,6 +176,7 @@ def _extract_bucketed(loader, n, net, batch_size, desc):
                 run(max(buckets, key=lambda k: len(buckets[k][0])))
         for key in list(buckets):
             run(key)
+        scatter()
     if out is None:                                # empty dataset / shard
         D = net._head_in_dim() if net.without_fc else net.out_dim
         out = torch.empty(0, D, dtype=torch.float32, device='cuda')
@@ -150,6 +194,7 @@ def extract_multiscale_features(dataset, scales, net, desc="Extract feats...", i
                         output=['img'], batch_size=1, threads=threads, shuffle=False)
     net.eval()
     rows = []
+    pool_ = StreamPool()            # the scales of an image (and the next image's) overlap on the device
     with torch.no_grad():
         for (img,) in tqdm.tqdm(loader, desc, total=len(dataset)):
             img = common.variables([img], net.iscuda)[0]              # [1, H, W, 3] uint8
@@ -158,8 +203,13 @@ def extract_multiscale_features(dataset, scales, net, desc="Extract feats...", i
             for sc in scales:
                 size = (W, H) if sc is None else sc.target_size((W, H))
                 x = img if size == (W, H) else ops.resize_bilinear_u8(img, size)
-                per_scale.append(net(x).reshape(1, -1))
-            rows.append(torch.cat(per_scale, dim=1))
+                per_scale.append(pool_.run(lambda: net(x).reshape(1, -1), x))
+            rows.append(per_scale)
+        pool_.join()
+        rows = [torch.cat(per_scale, dim=1) for per_scale in rows]
+    if not rows:
+        D = net._head_in_dim() if net.without_fc else net.out_dim
+        return torch.empty(0, len(scales) * D, dtype=torch.float32, device='cuda')
     return _check_finite(torch.cat(rows, dim=0), net)
 
 
