@@ -1,0 +1,143 @@
+// window_probe.hip - do L2-hit loads share the per-CU request window with HBM misses?
+//
+// The 1024 -> 256 conv1 of layer3 (conv_persist.hip) moves 32 KB of pixels (HBM) + 32 KB of weights (a 512 KB panel,
+// always an L2 hit) per K-step and runs at ~27 GB/s per CU for the sum.  This probe streams the same two kinds of
+// LDS-DMA traffic from one 512-thread workgroup per CU and varies (a) who issues what and (b) how many stages are in
+// flight, to tell "one in-order window per CU, hits queue behind misses" from "hits are cheap when other waves issue them":
+//   px    : 32 KB of unique HBM bytes per step, all 8 waves, 4 DMA instructions per lane
+//   px+w  : the same + 32 KB of a shared 512 KB buffer per step, every wave issues both kinds (what the kernel does)
+//   split : waves 0-3 issue the pixels (8 per lane), waves 4-7 the weights (8 per lane)
+//   w     : the shared buffer only
+//   px_d/w1: waves 0-3 keep DEPTH pixel stages in flight, waves 4-7 fetch the weights of step s at step s (one stage)
+// DEPTH = stages in flight per wave (the wait before step s leaves DEPTH - 1 newer stages outstanding).
+//   hipcc --offload-arch=gfx950 -O3 window_probe.hip -o window_probe && ./window_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#define LDSP __attribute__((address_space(3)))
+
+template <int MODE, int DEPTH>
+__global__ void __launch_bounds__(512) probe(const char* __restrict__ px, size_t px_per_wg, const char* __restrict__ w,
+                                             uint32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int steps = (int)(px_per_wg / 32768);
+    const __amdgpu_buffer_rsrc_t rp =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(px + (size_t)blockIdx.x * px_per_wg), 0, (int)px_per_wg, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 512 * 1024, 0x00020000);
+    constexpr int SLOTS = DEPTH;   // the barrier after the read frees stage s's slot before stage s + DEPTH goes out
+    constexpr int PER = (MODE == 1 || MODE == 2 || MODE == 4) ? 8 : 4;   // DMA instructions per lane per step
+    uint32_t acc = 0;
+    auto issue = [&](int s) {
+        char* slot = smem + (s % SLOTS) * 32768 * (MODE == 0 || MODE == 3 ? 1 : 2);
+        if (MODE == 0 || MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (LDSP void*)(slot + (k * 8 + wave) * 1024), 16,
+                                                         (uint32_t)((k * 8 + wave) * 1024 + lane * 16), s * 32768, 0, 0);
+        }
+        if (MODE == 1 || MODE == 3) {
+            char* ws = slot + (MODE == 1 ? 32768 : 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDSP void*)(ws + (k * 8 + wave) * 1024), 16,
+                                                         (uint32_t)((k * 8 + wave) * 1024 + lane * 16), (s & 15) * 32768, 0, 0);
+        }
+        if (MODE == 2) {
+            if (wave < 4) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (LDSP void*)(slot + (k * 4 + wave) * 1024), 16,
+                                                             (uint32_t)((k * 4 + wave) * 1024 + lane * 16), s * 32768, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDSP void*)(slot + 32768 + (k * 4 + wave - 4) * 1024), 16,
+                                                             (uint32_t)((k * 4 + wave - 4) * 1024 + lane * 16), (s & 15) * 32768, 0, 0);
+            }
+        }
+    };
+    if (MODE == 4) {
+        // deep pixels, shallow weights: waves 0-3 keep DEPTH pixel stages in flight, waves 4-7 fetch step s's weights at step s
+        char* wbase = smem + DEPTH * 32768;
+        auto issue_px = [&](int s) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (LDSP void*)(smem + (s % DEPTH) * 32768 + (k * 4 + wave) * 1024), 16,
+                                                         (uint32_t)((k * 4 + wave) * 1024 + lane * 16), s * 32768, 0, 0);
+        };
+        if (wave < 4) for (int s = 0; s < DEPTH - 1 && s < steps; ++s) issue_px(s);
+        for (int s = 0; s < steps; ++s) {
+            if (wave < 4) {
+                if (s + DEPTH - 1 < steps) issue_px(s + DEPTH - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"((DEPTH - 1) * 8) : "memory");
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDSP void*)(wbase + (k * 4 + wave - 4) * 1024), 16,
+                                                             (uint32_t)((k * 4 + wave - 4) * 1024 + lane * 16), (s & 15) * 32768, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            acc ^= *(const uint32_t*)(smem + (s % DEPTH) * 32768 + wave * 1024 + lane * 4) ^ *(const uint32_t*)(wbase + wave * 1024 + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (acc == 0x12345u) out[0] = 1;
+        return;
+    }
+    for (int s = 0; s < DEPTH - 1 && s < steps; ++s) issue(s);
+    for (int s = 0; s < steps; ++s) {
+        if (s + DEPTH - 1 < steps) issue(s + DEPTH - 1);
+        // step s must have landed; DEPTH - 1 newer stages of PER instructions each may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((DEPTH - 1) * PER) : "memory");
+        __builtin_amdgcn_s_barrier();   // like the kernels: a stage is consumed by every wave
+        acc ^= *(const uint32_t*)(smem + (s % SLOTS) * 32768 * (MODE == 0 || MODE == 3 ? 1 : 2) + wave * 1024 + lane * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // slot free for the stage issued next iteration
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 0x12345u) out[0] = 1;
+}
+
+template <int MODE, int DEPTH>
+static void run(const char* name, const char* px, size_t bytes, const char* w, uint32_t* out, int cus) {
+    const int lds = MODE == 4 ? (DEPTH + 1) * 32768 : DEPTH * 32768 * (MODE == 0 || MODE == 3 ? 1 : 2);
+    if (lds > 160 * 1024) return;
+    hipFuncSetAttribute((const void*)probe<MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const size_t per_wg = bytes / cus / 32768 * 32768;
+    float best = 1e9f;
+    for (int it = 0; it < 5; ++it) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((probe<MODE, DEPTH>), dim3(cus), dim3(512), lds, 0, px, per_wg, w, out);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double pxb = MODE == 3 ? 0.0 : (double)per_wg * cus, wb = MODE == 0 ? 0.0 : (double)per_wg * cus;
+    printf("%-7s depth %d: %.3f ms  HBM pixels %.0f GB/s (%.1f GB/s per CU)  L2 weights %.0f GB/s  sum per CU %.1f GB/s\n", name, DEPTH,
+           best, pxb / best / 1e6, pxb / best / 1e6 / cus, wb / best / 1e6, (pxb + wb) / best / 1e6 / cus);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+int main() {
+    const size_t bytes = 4ull << 30;
+    char *a, *w; uint32_t* out;
+    hipMalloc(&a, bytes); hipMalloc(&w, 512 * 1024); hipMalloc(&out, 64);
+    hipMemset(a, 1, bytes); hipMemset(w, 2, 512 * 1024);
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0, 1>("px", a, bytes, w, out, cus); run<0, 2>("px", a, bytes, w, out, cus);
+        run<0, 3>("px", a, bytes, w, out, cus); run<0, 4>("px", a, bytes, w, out, cus);
+        run<1, 1>("px+w", a, bytes, w, out, cus); run<1, 2>("px+w", a, bytes, w, out, cus);
+        run<2, 1>("split", a, bytes, w, out, cus); run<2, 2>("split", a, bytes, w, out, cus);
+        run<4, 1>("px_d/w1", a, bytes, w, out, cus); run<4, 2>("px_d/w1", a, bytes, w, out, cus);
+        run<4, 3>("px_d/w1", a, bytes, w, out, cus); run<4, 4>("px_d/w1", a, bytes, w, out, cus);
+        run<3, 1>("w", a, bytes, w, out, cus); run<3, 2>("w", a, bytes, w, out, cus); run<3, 4>("w", a, bytes, w, out, cus);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { printf("FAILED\n"); return 1; }
+    return 0;
+}
