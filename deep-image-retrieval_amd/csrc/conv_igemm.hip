@@ -485,7 +485,7 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT(128, 128, 2, 2, 3, 64, "128x128_w2x2_s3"),
     DIR_VARIANT16(128, 64, 2, 2, 4, "128x64_w2x2_s4"),
     DIR_VARIANT(256, 128, 4, 2, 3, 64, "256x128_w4x2_s3"),
-    DIR_VARIANT(128, 256, 2, 4, 3, 64, "128x256_w2x4_s3"),
+    DIR_VARIANT_DUAL(128, 256, 2, 4, 3, 64, "128x256_w2x4_s3"),
     DIR_VARIANT16(256, 64, 4, 1, 3, "256x64_w4x1_s3"),
     DIR_VARIANT(256, 256, 4, 2, 4, 32, "256x256_w4x2_s4_k32"),
     DIR_VARIANT(256, 256, 4, 2, 3, 32, "256x256_w4x2_s3_k32"),
@@ -511,6 +511,9 @@ static const ConvVariant kVariants[] = {
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}, {nullptr, nullptr}},
     // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
     {"256x256_persist1x1_x3", 256, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 4, {nullptr, nullptr}, {nullptr, nullptr}},
+    // persistent 128x256 tile, loader waves feed ONE three-slot K ring over all the tiles of a workgroup, consumer waves
+    // multiply; 1x1 convs without a residual (conv_ring.hip)
+    {"128x256_ring1x1", 128, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 7, {nullptr, nullptr}, {nullptr, nullptr}},
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
     {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}, {nullptr, nullptr}},
 };
@@ -528,6 +531,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 2) return conv1x1_persist_admissible(a);
     if (cv.kind == 4) return conv1x1_persist_admissible(a) && a.res == nullptr;   // the deep-X form has no residual path
     if (cv.kind == 3) return conv1x1_wreg_admissible(a);
+    if (cv.kind == 7) return conv1x1_ring_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
@@ -565,7 +569,7 @@ int conv_pick_variant(const ConvArgs& a) {
     }
     const int T = a.Ktot / 64;
     struct Cand { const char* name; int wg_per_cu; };
-    Cand c[11];
+    Cand c[12];
     int n = 0;
     {
         // 3x3 stride 1 over >= 128 channels (conv2 of layer2 / 3 / 4): 512 pixels x 128 channels per workgroup with
@@ -588,6 +592,10 @@ int conv_pick_variant(const ConvArgs& a) {
         // 16-wave implicit-GEMM tile where it is not admissible (stride 2, odd widths) or too few tiles
         static const bool no_ps = getenv("DIRTORCH_AMD_NO_PATCHS") != nullptr;  // A/B and bisecting
         if (a.R * a.S > 1 && !no_ps) c[n++] = {"256x256_patch3x3s", 1};
+        // (conv_ring.hip's 128x256_ring1x1 - split loader / consumer waves - ties the persistent kernel on these layers
+        // inside the network, gpurun_out/r3f-r3h: it stays a tuner candidate; DIRTORCH_AMD_RING=1 puts it first, for A/B)
+        static const bool ring = getenv("DIRTORCH_AMD_RING") != nullptr;
+        if (a.R * a.S == 1 && !a.res && ring) c[n++] = {"128x256_ring1x1", 1};
         c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
@@ -629,7 +637,9 @@ int conv_pick_dual_variant(const ConvArgs& a) {
     // one instantiation carries the form: 256x256, 8 waves (the two-workgroups-per-CU k32 tile goes over
     // 128 VGPRs with the second source's offsets and loses its occupancy)
     if (a.Cout % 256 != 0 || (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192) return -1;
-    const int v = find_variant("256x256_w4x2");
+    // DIRTORCH_AMD_DUAL_VARIANT=<name> picks another two-source instantiation (A/B and bisecting; read once)
+    static const char* forced = getenv("DIRTORCH_AMD_DUAL_VARIANT");
+    const int v = find_variant(forced ? forced : "256x256_w4x2");
     if (v < 0 || kVariants[v].launch_dual[0] == nullptr || a.Cout % kVariants[v].BN != 0) return -1;
     return v;
 }
@@ -742,6 +752,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
                    : cv.kind == 4 ? conv1x1_persist_launch(a, dtype, stream, true)
                    : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)
+                   : cv.kind == 7 ? conv1x1_ring_launch(a, dtype, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)

@@ -6,9 +6,8 @@
 //     rank(p) = #{ j : j ranks before p } - #{ junk j : j ranks before p },
 // where "j ranks before p" is (s_j > s_p) or (s_j == s_p and j > p) - the order of
 // np.argsort(scores)[::-1] with ties resolved by descending index.  The first term is a dense count
-// over the row (this kernel, HBM-bound: each score read once per 1024 probes); the second involves
-// only the few hundred listed images of the query and is finished on the host from the probe scores
-// this kernel also returns.
+// over the row (rank_counts below, HBM-bound: each score read once per 4096 probes); the second involves
+// only the few hundred listed images of the query (revisitop_ap_kernel at the end of this file).
 #include "dir_common.h"
 #include "pointwise.h"
 
@@ -16,50 +15,160 @@
 
 namespace dir {
 
-constexpr int kRankChunk = 4096;  // scores staged per workgroup (16 KiB of LDS)
-constexpr int kMaxProbes = 1024;  // probes per query per launch (4 per lane)
+// Work: the count of a probe depends on that probe and the row only, and "j ranks before p" is a comparison of the
+// 64-bit keys (score mapped to an order-preserving uint32, index): key_j > key_p.  With the P probes of a query SORTED
+// by key, an item ranks before exactly the first k_j = lower_bound(key_j) of them, so one binary search per score
+// (log2 P LDS reads) and a histogram of k_j replace the P comparisons per score of a direct count:
+//     count[probe at sorted position i] = #{ j : k_j > i } = sum_{k > i} hist[k].
+//   rank_sort_kernel      one workgroup per (query, slice of <= 4096 probes): bitonic sort of (key, slot) in LDS;
+//                         writes the permutation into the probe_scores slice (as integers - no scratch buffer)
+//   rank_hist_kernel      one workgroup per (16384 scores, query): keys of the slice rebuilt through the permutation
+//                         into LDS, every score read ONCE (coalesced), binary search, LDS histogram, non-zero bins
+//                         added to counts[q][sorted position] (bin k lives at k - 1; bin 0 is never needed)
+//   rank_finalize_kernel  one workgroup per (query, slice): suffix sums of the bins, scattered to the probes' own
+//                         slots; probe_scores gets scores[q][probe]
+// HBM-bound: N*4 B per query per slice of probes.  A NaN score ranks before nothing and nothing ranks before a NaN
+// probe (every comparison of the reference's ordering is false); -0 == +0 as in the float compare.
+constexpr int kRankChunk = 16384;  // scores per workgroup
+constexpr int kMaxProbes = 4096;   // probes per query per launch (keys 32 KiB + bins 16 KiB of LDS)
+constexpr uint64_t kKeyMax = ~0ull;
 
-__global__ void __launch_bounds__(256) rank_counts_kernel(const float* __restrict__ scores, int lds,
-                                                         int N, const int* __restrict__ probe_idx,
-                                                         int P, int ldp, int* __restrict__ counts,
-                                                         float* __restrict__ probe_scores) {
-    __shared__ __attribute__((aligned(16))) float tile[kRankChunk];
-    const int q = blockIdx.y;
-    const int j0 = blockIdx.x * kRankChunk;
+__device__ __forceinline__ uint64_t rank_key(float s, int idx) {
+    if (s == 0.f) s = 0.f;                               // -0 -> +0: they compare equal
+    const uint32_t b = __builtin_bit_cast(uint32_t, s);
+    const uint32_t u = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // order-preserving for every non-NaN float
+    return ((uint64_t)u << 32) | (uint32_t)idx;
+}
+
+// probe_idx / perm_out point at the slice: [Q][ldp] rows, P (<= kMaxProbes) columns in use, P2 = pow2 >= P.
+__global__ void __launch_bounds__(256) rank_sort_kernel(const float* __restrict__ scores, int lds,
+                                                       const int* __restrict__ probe_idx, int P, int P2, int ldp,
+                                                       int* __restrict__ perm_out) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    uint64_t* keys = (uint64_t*)rsm;
+    int* slot = (int*)(rsm + (size_t)P2 * 8);
+    const int q = blockIdx.x;
     const float* row = scores + (size_t)q * lds;
-    const int n = min(kRankChunk, N - j0);
-    for (int i = threadIdx.x; i < kRankChunk; i += 256)
-        tile[i] = i < n ? row[j0 + i] : -INFINITY;  // -inf never ranks before a finite probe
-
-    int pidx[4];
-    float ps[4];
-    int cnt[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int p = threadIdx.x + 256 * u;
-        pidx[u] = p < P ? probe_idx[(size_t)q * ldp + p] : -1;
-        ps[u] = pidx[u] >= 0 ? row[pidx[u]] : INFINITY;
-        cnt[u] = 0;
+    for (int i = threadIdx.x; i < P2; i += 256) {
+        const int idx = i < P ? probe_idx[(size_t)q * ldp + i] : -1;
+        uint64_t k = kKeyMax;                            // unused slots and NaN probes sort last: their suffix sums are 0
+        if (idx >= 0) {
+            const float s = row[idx];
+            if (s == s) k = rank_key(s, idx);
+        }
+        keys[i] = k;
+        slot[i] = i;
     }
     __syncthreads();
-    const int nu = (P + 255) / 256;  // probe slots in use (uniform)
-    for (int i = 0; i < kRankChunk; i += 4) {
-        const f32x4_t s4 = *(const f32x4_t*)(tile + i);  // same address for every lane: broadcast
+    for (int len = 2; len <= P2; len <<= 1)
+        for (int st = len >> 1; st > 0; st >>= 1) {
+            for (int i = threadIdx.x; i < P2 / 2; i += 256) {
+                const int lo = ((i / st) * st * 2) + (i % st), hi = lo + st;
+                const bool up = ((lo & len) == 0);
+                const uint64_t a = keys[lo], b = keys[hi];
+                const int sa = slot[lo], sb = slot[hi];
+                // ties between equal keys (a probe listed twice, the padding) break on the slot: a total order
+                const bool gt = a > b || (a == b && sa > sb);
+                if (gt == up) {
+                    keys[lo] = b, keys[hi] = a;
+                    slot[lo] = sb, slot[hi] = sa;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < P; i += 256) perm_out[(size_t)q * ldp + i] = slot[i];   // padding sorts behind every real slot
+}
+
+__global__ void __launch_bounds__(256) rank_hist_kernel(const float* __restrict__ scores, int lds, int N,
+                                                       const int* __restrict__ probe_idx, int P, int P2, int ldp,
+                                                       const int* __restrict__ perm, int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    uint64_t* keys = (uint64_t*)rsm;
+    int* hist = (int*)(rsm + (size_t)P2 * 8);
+    const int q = blockIdx.y;
+    const float* row = scores + (size_t)q * lds;
+    for (int i = threadIdx.x; i < P2; i += 256) {
+        uint64_t k = kKeyMax;
+        if (i < P) {
+            const int sl = perm[(size_t)q * ldp + i];
+            const int idx = probe_idx[(size_t)q * ldp + sl];
+            if (idx >= 0) {
+                const float s = row[idx];
+                if (s == s) k = rank_key(s, idx);
+            }
+        }
+        keys[i] = k;
+        hist[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t kmin = keys[0];
+    const long j0 = (long)blockIdx.x * kRankChunk;
+    constexpr int U = 8;
+    for (int base = 0; base < kRankChunk; base += 256 * U) {
+        float v[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = j0 + i + e;
+        for (int u = 0; u < U; ++u) {
+            const long j = j0 + base + u * 256 + threadIdx.x;
+            v[u] = j < N ? row[j] : NAN;
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < nu) cnt[u] += (s4[e] > ps[u]) || (s4[e] == ps[u] && j > pidx[u]);
+        for (int u = 0; u < U; ++u) {
+            const long j = j0 + base + u * 256 + threadIdx.x;
+            if (!(v[u] == v[u])) continue;               // NaN (and the tail past N) ranks before nothing
+            const uint64_t kj = rank_key(v[u], (int)j);
+            if (kj <= kmin) continue;                    // before no probe: bin 0
+            int pos = 0;                                 // lower bound in a power-of-two table
+            for (int st = P2 >> 1; st > 0; st >>= 1)
+                if (keys[pos + st - 1] < kj) pos += st;
+            // pos >= 1 here.  The last table entry is never passed unless it is a real key below kj
+            if (pos < P2 && keys[pos] < kj) ++pos;
+            atomicAdd(&hist[pos - 1], 1);
         }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int p = threadIdx.x + 256 * u;
-        if (p < P && pidx[u] >= 0) {
-            if (cnt[u]) atomicAdd(counts + (size_t)q * ldp + p, cnt[u]);
-            if (blockIdx.x == 0) probe_scores[(size_t)q * ldp + p] = ps[u];
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += 256)
+        if (hist[i]) atomicAdd(counts + (size_t)q * ldp + i, hist[i]);
+}
+
+__global__ void __launch_bounds__(256) rank_finalize_kernel(const float* __restrict__ scores, int lds,
+                                                           const int* __restrict__ probe_idx, int P, int ldp,
+                                                           int* __restrict__ counts, float* __restrict__ probe_scores) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    int* bins = (int*)rsm;             // [P] bin k at k - 1; becomes the suffix sums
+    int* slot = bins + P;              // [P] sorted position -> slot
+    __shared__ int carry;
+    const int q = blockIdx.x;
+    const float* row = scores + (size_t)q * lds;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        bins[i] = counts[(size_t)q * ldp + i];
+        slot[i] = __builtin_bit_cast(int, probe_scores[(size_t)q * ldp + i]);
+    }
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    // suffix sums, 256 positions at a time from the top: S[i] = sum_{m >= i} bins[m]
+    __shared__ int part[256];
+    for (int top = ((P + 255) / 256) * 256; top > 0; top -= 256) {
+        const int i = top - 256 + (int)threadIdx.x;
+        const int x = i < P ? bins[i] : 0;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {   // inclusive suffix scan (Hillis-Steele)
+            const int y = (int)threadIdx.x + d < 256 ? part[threadIdx.x + d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += y;
+            __syncthreads();
         }
+        const int c = carry;
+        __syncthreads();
+        if (i < P) bins[i] = part[threadIdx.x] + c;
+        if (threadIdx.x == 0) carry = c + part[0];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const int sl = slot[i];
+        const int idx = probe_idx[(size_t)q * ldp + sl];
+        counts[(size_t)q * ldp + sl] = idx >= 0 ? bins[i] : 0;
+        probe_scores[(size_t)q * ldp + sl] = idx >= 0 ? row[idx] : 0.f;
     }
 }
 
@@ -68,11 +177,22 @@ int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx
     if (Q <= 0 || P <= 0 || N <= 0) return DIR_OK;
     if (lds < N) return fail(DIR_ERR_INVALID, "rank_counts: lds < N");
     DIR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)Q * P * sizeof(int), stream));
-    const dim3 grid((N + kRankChunk - 1) / kRankChunk, Q);
-    for (int p0 = 0; p0 < P; p0 += kMaxProbes) {   // 1024 probes per query per launch, column slices of [Q][P]
+    static std::atomic<uint64_t> attr_sort{0}, attr_hist{0}, attr_fin{0};
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)rank_sort_kernel, kMaxProbes * 12, attr_sort));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)rank_hist_kernel, kMaxProbes * 12, attr_hist));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)rank_finalize_kernel, kMaxProbes * 8, attr_fin));
+    const long chunks = ((long)N + kRankChunk - 1) / kRankChunk;
+    for (int p0 = 0; p0 < P; p0 += kMaxProbes) {   // 4096 probes per query per pass, column slices of [Q][P]
         const int np = P - p0 < kMaxProbes ? P - p0 : kMaxProbes;
-        hipLaunchKernelGGL(rank_counts_kernel, grid, dim3(256), 0, stream, scores, lds, N, probe_idx + p0, np, P,
-                           counts + p0, probe_scores + p0);
+        int p2 = 2;
+        while (p2 < np) p2 <<= 1;
+        int* perm = (int*)(probe_scores + p0);     // the slice of probe_scores holds the permutation until the last kernel
+        hipLaunchKernelGGL(rank_sort_kernel, dim3(Q), dim3(256), (size_t)p2 * 12, stream, scores, lds, probe_idx + p0, np,
+                           p2, P, perm);
+        hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)chunks, Q), dim3(256), (size_t)p2 * 12, stream, scores, lds, N,
+                           probe_idx + p0, np, p2, P, perm, counts + p0);
+        hipLaunchKernelGGL(rank_finalize_kernel, dim3(Q), dim3(256), (size_t)np * 8, stream, scores, lds, probe_idx + p0, np,
+                           P, counts + p0, probe_scores + p0);
         DIR_HIP_CHECK(hipGetLastError());
     }
     return DIR_OK;

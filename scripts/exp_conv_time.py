@@ -17,6 +17,8 @@ SHAPES = {   # name: (B, H, W, Cin, Cout, k, stride, pad, residual)
     'l2.conv2': (32, 128, 128, 128, 128, 3, 1, 1, False),
     'l2.conv3': (32, 128, 128, 128, 512, 1, 1, 0, True),
     'l4.conv2': (32, 32, 32, 512, 512, 3, 1, 1, False),
+    'l4.conv1': (32, 32, 32, 2048, 512, 1, 1, 0, False),
+    'l3.0.conv1': (32, 128, 128, 512, 256, 1, 1, 0, False),
 }
 names = []
 n = _lib.load().dir_conv_variant_count()
@@ -28,7 +30,10 @@ ZEROS = os.environ.get('EXP_ZEROS') == '1'   # zero-filled operands: same instru
 want = sys.argv[1:] or ['256x256_w4x2', '256x256_w4x4', '256x256_w4x2_s3_k32', '256x256_w4x2_s4_k32',
                         '256x256_persist1x1', '128x256_w2x4_s3_k32', '256x128_w4x2_s3_k32', '128x128_w2x2']
 print('lib', _lib.LIB_PATH)
+ONLY = os.environ.get('EXP_SHAPES')   # comma-separated subset of SHAPES
 for sname, (B, H, W, Cin, Cout, k, st, pad, res) in SHAPES.items():
+    if ONLY and sname not in ONLY.split(','):
+        continue
     x = (torch.randn(B, H, W, Cin, device='cuda') * 0.5).to(torch.bfloat16)
     w = (torch.randn(Cout, k, k, Cin, device='cuda') * 0.02).to(torch.bfloat16)
     if ZEROS:

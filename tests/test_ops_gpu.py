@@ -48,6 +48,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
         return k == 3 and stride == 1 and pad == 1 and Cin in (256, 512) and Cout % 256 == 0
     if 'patch3x3' in name:
         return k == 3 and stride == 1 and pad == 1 and Cin == Cout == bn
+    if 'ring1x1' in name:                # loader / consumer K ring: 1x1 without a residual, 256-channel output tiles
+        return k == 1 and pad == 0 and Cout % 256 == 0 and Cout <= 2048 and Cin >= 128 and not has_res
     if 'persist1x1_x3' in name:          # the deep-X form has no residual path
         return k == 1 and pad == 0 and Cout % 256 == 0 and Cin >= 128 and not has_res
     if 'persist1x1' in name:
@@ -105,6 +107,8 @@ CONV_SHAPES = [
     ('3x3_tall_37x33', 1, 37, 33, 128, 256, 3, 1, 1, True, True),        # three 16-row tiles (16, 16, 5) x two 32-column tiles (32, 1)
     ('1x1_wreg_k256', 2, 17, 13, 256, 1024, 1, 1, 0, True, True),       # 442 pixels: ragged last tile of 64
     ('1x1_wreg_k128_norelu', 3, 20, 20, 128, 512, 1, 1, 0, True, False),
+    ('1x1_ring_k1024', 2, 23, 29, 1024, 256, 1, 1, 0, False, True),      # 16 K-steps, 11 pixel tiles of 128 (ragged last)
+    ('1x1_ring_two_ntiles', 1, 19, 21, 1024, 512, 1, 1, 0, False, False), # two channel tiles per pixel tile, no ReLU
 ]
 
 
@@ -507,6 +511,37 @@ def test_persistent_deep_x_ring_at_scale(B, HW, Cin, Cout, stride):
         int(bad.sum()), bad.flatten(0, 2).any(dim=1).nonzero()[:8].flatten().tolist())
     again = ops.conv_bn_act(x, w, bias, None, variant=names.index('256x256_persist1x1_x3'), **kw)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize('B,HW,Cin,Cout,stride', [(32, 64, 1024, 256, 1), (31, 63, 1024, 256, 1), (5, 33, 2048, 512, 1),
+                                                  (7, 127, 1024, 256, 2), (16, 32, 2048, 512, 1), (1, 20, 1024, 256, 1),
+                                                  (3, 64, 1024, 256, 1), (32, 64, 1024, 512, 1), (9, 65, 256, 512, 1)],
+                         ids=['layer3.conv1_b32', 'ragged', 'two_ntiles_k2048_ragged', 'strided', 'layer4.conv1',
+                              'fewer_tiles_than_cus', 'one_or_two_tiles_per_workgroup', 'layer4.0.conv1', 'short_k'])
+def test_ring_kernel_at_scale(B, HW, Cin, Cout, stride):
+    """conv_ring.hip (loader waves feed one three-slot K ring over ALL the tiles of a persistent workgroup, consumer
+    waves multiply and store straight from the accumulators) where workgroups walk one, two or several 128-pixel
+    tiles and the ring wraps across tile boundaries: element by element against the naive device checker, bit for bit
+    against the 2-slot persistent kernel (same K order and fp32 sums), and run to run."""
+    ops = _ops()
+    names = ops.conv_variant_names()
+    for dname, dt in DTYPES.items():
+        g = torch.Generator(device='cuda').manual_seed(47)
+        x = torch.randn(B, HW, HW, Cin, generator=g, device='cuda').to(dt)
+        w = (torch.randn(Cout, 1, 1, Cin, generator=g, device='cuda') * (2.0 / Cin) ** 0.5).to(dt)
+        bias = torch.randn(Cout, generator=g, device='cuda') * 0.1
+        kw = dict(stride=stride, pad=0, relu=True)
+        got = ops.conv_bn_act(x, w, bias, None, variant=names.index('128x256_ring1x1'), **kw)
+        old = ops.conv_bn_act(x, w, bias, None, variant=names.index('256x256_persist1x1'), **kw)
+        ref = ops.conv_bn_act(x, w, bias, None, naive=True, **kw).float()
+        err = (got.float() - ref).abs()
+        tol = RTOL[dname] * ref.abs() + RTOL[dname] * ref.abs().mean()
+        bad = (err > tol)
+        assert int(bad.sum()) == 0, '%s: bad elements %d, first bad pixel rows %s' % (
+            dname, int(bad.sum()), bad.flatten(0, 2).any(dim=1).nonzero()[:8].flatten().tolist())
+        assert torch.equal(got, old), dname
+        again = ops.conv_bn_act(x, w, bias, None, variant=names.index('128x256_ring1x1'), **kw)
+        assert torch.equal(got, again), dname
 
 
 @pytest.mark.parametrize('shape', [(63, 128, 128, 512), (8, 128, 128, 512), (8, 64, 256, 1024)],

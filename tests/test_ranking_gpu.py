@@ -52,6 +52,61 @@ def test_rank_counts_kernel_matches_argsort():
                 assert s[q, k] == scores[q, probe[q, k]]
 
 
+def _host_counts(scores, probe):
+    """counts[q][k] by the definition in include/dir_engine.h: items with a greater score, or an equal score and a
+    larger index (float compares: NaN ranks before nothing, nothing ranks before NaN, -0 == +0)."""
+    Q, P = probe.shape
+    out = np.zeros((Q, P), np.int64)
+    j = np.arange(scores.shape[1])
+    for q in range(Q):
+        for k in range(P):
+            p = probe[q, k]
+            if p >= 0:
+                with np.errstate(invalid='ignore'):
+                    out[q, k] = np.count_nonzero((scores[q] > scores[q, p]) | ((scores[q] == scores[q, p]) & (j > p)))
+    return out
+
+
+@pytest.mark.parametrize('P', [1, 2, 200, 1024, 4096, 4097, 9001])
+def test_rank_counts_probe_slices_and_heavy_ties(P):
+    """Every probe-table size class of the sorted-probe kernels (one probe, powers of two, one past a slice of 4096,
+    several slices) on scores with many exact ties (values from a small set), so that the (score, index) order is
+    exercised everywhere; unused slots scattered through the rows."""
+    from dirtorch_amd import ops
+    r = np.random.RandomState(P)
+    Q, N = 3, 40003
+    scores = (r.randint(-6, 7, size=(Q, N)) / 4.0).astype(np.float32)      # 13 distinct values: ties everywhere
+    scores[1] = r.standard_normal(N).astype(np.float32)                    # and one row without
+    probe = np.stack([r.choice(N, P, replace=False) for _ in range(Q)]).astype(np.int32)
+    probe[2, ::7] = -1
+    c, s = ops.rank_counts(torch.from_numpy(scores).cuda(), torch.from_numpy(probe).cuda())
+    c, s = c.cpu().numpy(), s.cpu().numpy()
+    assert (c == _host_counts(scores, probe)).all()
+    valid = probe >= 0
+    assert (s[valid] == np.take_along_axis(scores, np.maximum(probe, 0), 1)[valid]).all() and (c[~valid] == 0).all()
+
+
+def test_rank_counts_special_values():
+    """NaN scores rank before nothing and nothing ranks before a NaN probe; -0 ties with +0 (index decides);
+    infinities order like floats; a probe listed twice gets the same count in both slots."""
+    from dirtorch_amd import ops
+    r = np.random.RandomState(3)
+    Q, N = 2, 20000
+    scores = r.standard_normal((Q, N)).astype(np.float32)
+    scores[0, [5, 17, 9000, 19999]] = [0.0, -0.0, 0.0, -0.0]
+    scores[0, [6, 7000]] = np.nan
+    scores[0, [8, 12000]] = [np.inf, -np.inf]
+    scores[1, ::3] = 0.0
+    scores[1, 1::3] = -0.0
+    probe = np.stack([r.choice(N, 64, replace=False) for _ in range(Q)]).astype(np.int32)
+    probe[0, :10] = [5, 17, 9000, 19999, 6, 7000, 8, 12000, 5, 8]          # incl. NaN probes and two duplicates
+    c, s = ops.rank_counts(torch.from_numpy(scores).cuda(), torch.from_numpy(probe).cuda())
+    c, s = c.cpu().numpy(), s.cpu().numpy()
+    assert (c == _host_counts(scores, probe)).all()
+    assert c[0, 4] == 0 and c[0, 5] == 0 and np.isnan(s[0, 4]) and np.isnan(s[0, 5])
+    assert c[0, 0] == c[0, 8] and c[0, 6] == c[0, 9] == 0                   # +inf: nothing ranks before it
+
+
 @pytest.mark.parametrize('classic', [False, True])
 def test_device_ap_equals_host_protocol(tmp_path, classic):
     from dirtorch_amd import ranking
