@@ -354,7 +354,7 @@ def bench_distractors(args, world, rank, dist):
                                'database sharded over the ranks, one all-gather of %s, similarity + device rank/AP'
                                % (N, Q, 'descriptor blocks' if args.exchange == 'descriptors' else 'score blocks'),
                    'exchange': args.exchange, 'rows_per_rank': rows, 'mAP_medium': round(float(np.mean([a['medium'] for a in aps])), 6)},
-        'roofline': {'bound': 'hbm', 'kernel': 'sim_split_kernel' if sim_rows >= 32768 else 'gemm_nt_f32',
+        'roofline': {'bound': 'hbm', 'kernel': ('sim_split_kernel' if os.environ.get('DIRTORCH_AMD_SIM_V1') else 'sim_split_lc_kernel') if sim_rows >= 32768 else 'gemm_nt_f32',
                      'achieved': round(sim_bytes / (sim_ms * 1e-3) / 1e9, 1) if sim_ms else None, 'peak': PEAK_HBM_GBS,
                      'unit': 'GB/s', 'frac': round(sim_bytes / (sim_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sim_ms else None,
                      'traffic': None, 'avg_launch_ms': round(sim_ms, 4), 'algorithmic_bytes_per_launch': sim_bytes,
@@ -381,6 +381,74 @@ def bench_distractors(args, world, rank, dist):
     print(json.dumps(out))
 
 
+def bench_multiscale(args, world, rank, dist):
+    """BASELINE configs[4]: ResNet-101 GeM, THREE-scale descriptors (x 0.7071 / 1 / 1.4142, dirtorch/test_dir.py:111-122
+    + utils/common.py:41-55) of 1200 x 1200 images, fp16, image-parallel over the ranks (replicated weights, each rank its
+    own contiguous image range, no data-path collective), ONE all-gather of the descriptor blocks at the end.  A step =
+    one batch of uint8 images resident in HBM -> Pillow-identical resize per scale (resize.hip) -> dir_forward per scale
+    -> GeM pooling over the scales + L2.  value = 3-scale images/s, whole job; scaling 'weak'."""
+    import synth
+    from dirtorch_amd import nets, ops
+    from dirtorch_amd.utils import common, transforms
+    net = nets.create_model(args.arch + '_rmac', pretrained='')
+    net.load_state_dict(synth.synth_state_dict(args.arch, seed=7))
+    net.compute_dtype = 'fp16'
+    net.cuda().eval()
+    B, S, K, Wm = args.ms_batch, args.ms_size, args.steps, args.warmup
+    g = torch.Generator(device='cuda').manual_seed(99 + rank)
+    img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda', generator=g)
+    scales = [transforms.Scale(0.7071), None, transforms.Scale(1.4142)]
+    sizes = [(S, S) if sc is None else sc.target_size((S, S)) for sc in scales]
+    shard = torch.empty(K * B, net.out_dim, device='cuda')
+
+    def step():
+        per_scale = []
+        for size in sizes:
+            x = img if size == (S, S) else ops.resize_bilinear_u8(img, size)
+            per_scale.append(net(x))
+        return common.l2_normalize(common.pool(per_scale, 'gem', 3))
+
+    for _ in range(max(Wm, 2)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        shard[k * B:(k + 1) * B] = step()
+    if dist is not None:
+        allb = torch.empty(world * K * B, net.out_dim, device='cuda')
+        dist.all_gather_into_tensor(allb, shard)                  # the one exchange step (RCCL)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    # ResNet-101 trunk: 448.76 GFLOP at 1200^2 (SURVEY section 8d), quadratic in the side
+    gflop = sum(448.76 * (s_[0] * s_[1]) / (1200.0 * 1200.0) for s_ in sizes)
+    ips = world * K * B / el
+    print(json.dumps({
+        'metric': 'images/sec 3-scale descriptor extraction (%s-GeM, %dx%d, scales 0.7071/1/1.4142)' % (args.arch, S, S),
+        'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+        'ms_per_step': round(el / K * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'fp16', 'data': 'synthetic',
+        'config': {'workload': 'configs[4]: %s-GeM multi-scale (3 scales %s) extraction of %dx%d uint8 images, fp16, '
+                               'image-parallel, one all-gather of descriptor blocks' % (args.arch, [s_[0] for s_ in sizes], S, S),
+                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim)},
+        'roofline': {'bound': 'mfma', 'kernel': 'whole step (three dir_forward passes + resize + pooling)',
+                     'achieved': round(ips / world * gflop / 1e3, 1), 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s',
+                     'frac': round(ips / world * gflop / 1e3 / PEAK_TFLOPS['fp16'], 4), 'traffic': None,
+                     'note': 'step-level figure: conv FLOPs of the three scales / step time; the per-kernel table is the '
+                             'extract workload\'s (same kernels, same layer shapes at 1024^2)'},
+        'cpu_baseline': None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -397,9 +465,11 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU legs (baseline + precision)')
     ap.add_argument('--no-precision', action='store_true',
                     help='skip the fp16 / strict-fp32 throughput and the parity-vs-oracle fields (config.precision)')
-    ap.add_argument('--workload', default='extract', choices=['extract', 'distractors'],
-                    help="extract = BASELINE configs[1] (default); distractors = configs[3]: a database of --db-rows "
+    ap.add_argument('--workload', default='extract', choices=['extract', 'distractors', 'multiscale'],
+                    help="extract = BASELINE configs[1] (default); multiscale = configs[4] (3 scales of 1200^2, fp16); distractors = configs[3]: a database of --db-rows "
                          "2048-d descriptors sharded over the ranks, ONE all-gather, Q x N similarity, device rank + AP")
+    ap.add_argument('--ms-batch', type=int, default=8, help='multiscale: images per GPU per step')
+    ap.add_argument('--ms-size', type=int, default=1200, help='multiscale: side of the (square) source images')
     ap.add_argument('--db-rows', type=int, default=1006322, help='distractors: database size (RParis6K + 1M)')
     ap.add_argument('--queries', type=int, default=70)
     ap.add_argument('--exchange', default='descriptors', choices=['descriptors', 'scores'],
@@ -427,8 +497,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
 
-    if args.workload == 'distractors':
-        bench_distractors(args, world, rank, dist)
+    if args.workload in ('distractors', 'multiscale'):
+        (bench_distractors if args.workload == 'distractors' else bench_multiscale)(args, world, rank, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -530,7 +600,7 @@ def main():
                 'note': 'frac = the largest-time-share kernel against ITS roof; whole step = step_mfma_frac of the MFMA peak',
                 # measured once on a pool box (profiles/r02_mfma_ceiling.txt): bare register-only MFMA loop, 8 waves/CU
                 'mfma_ceiling_measured_tflops': {'random_operands': 1582, 'zero_operands': 2285},
-                'hbm_ceiling_measured_gbs': {'read': 6305, 'copy_1to1': 5147},   # profiles/r02_hbm_ceiling.txt
+                'hbm_ceiling_measured_gbs': {'read': 6305, 'copy_1to1': 5147, 'read_write_4to1': 5100},   # profiles/r02_hbm_ceiling.txt, r03_read_store_mix_probe.txt
                 'launches': dn, 'avg_launch_ms': round(dms / dn, 5),
                 'flops_per_launch': dfl / dn, 'algorithmic_bytes_per_launch': dby / dn,
                 'kernel_tflops': round(tflops, 2), 'kernel_gbs': round(gbs, 1),

@@ -485,7 +485,7 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT(128, 128, 2, 2, 3, 64, "128x128_w2x2_s3"),
     DIR_VARIANT16(128, 64, 2, 2, 4, "128x64_w2x2_s4"),
     DIR_VARIANT(256, 128, 4, 2, 3, 64, "256x128_w4x2_s3"),
-    DIR_VARIANT_DUAL(128, 256, 2, 4, 3, 64, "128x256_w2x4_s3"),
+    DIR_VARIANT(128, 256, 2, 4, 3, 64, "128x256_w2x4_s3"),
     DIR_VARIANT16(256, 64, 4, 1, 3, "256x64_w4x1_s3"),
     DIR_VARIANT(256, 256, 4, 2, 4, 32, "256x256_w4x2_s4_k32"),
     DIR_VARIANT(256, 256, 4, 2, 3, 32, "256x256_w4x2_s3_k32"),
@@ -637,9 +637,9 @@ int conv_pick_dual_variant(const ConvArgs& a) {
     // one instantiation carries the form: 256x256, 8 waves (the two-workgroups-per-CU k32 tile goes over
     // 128 VGPRs with the second source's offsets and loses its occupancy)
     if (a.Cout % 256 != 0 || (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192) return -1;
-    // DIRTORCH_AMD_DUAL_VARIANT=<name> picks another two-source instantiation (A/B and bisecting; read once)
-    static const char* forced = getenv("DIRTORCH_AMD_DUAL_VARIANT");
-    const int v = find_variant(forced ? forced : "256x256_w4x2");
+    // (a two-source instantiation of the 3-slot 128x256 tile, two stages in flight, measured 0.39 / 0.29 / 0.22 ms
+    // against 0.31 / 0.24 / 0.19 ms on the first blocks of layers 2 / 3 / 4 - gpurun_out/r3i - and was removed)
+    const int v = find_variant("256x256_w4x2");
     if (v < 0 || kVariants[v].launch_dual[0] == nullptr || a.Cout % kVariants[v].BN != 0) return -1;
     return v;
 }

@@ -198,6 +198,145 @@ __global__ void __launch_bounds__(512) sim_split_kernel(const float* __restrict_
     }
 }
 
+// Timing-only experiment builds (scripts/exp_sim.sh): -DDIR_SIM_ABL=<bits> - 1 = no database DMA, 2 = no query DMA,
+// 4 = consumers only take the barriers.  Results are NOT valid scores.
+#ifndef DIR_SIM_ABL
+#define DIR_SIM_ABL 0
+#endif
+
+// ---- loader / consumer form (default) -----------------------------------------------------------------------------
+// Same tiles, stages, fragments and arithmetic as sim_split_kernel above (bit-identical scores), with the work split by
+// wave role: on a memory-bound CU the request queue is full, every LDS-DMA instruction holds its wave at issue until the
+// queue drains, and in the kernel above the eight waves that issue the next slab are the eight waves that should be
+// splitting and multiplying this one - the two phases serialise (the same finding as conv_ring.hip,
+// profiles/r03_ring_ablation.txt).  Here a workgroup has TWELVE waves (148 VGPRs: three waves per SIMD fit): waves 0-7
+// are the consumers of the old kernel (one 32-row strip each, no memory ops until the final score store), waves 8-11
+// only issue LDS-DMA - 8 database pieces + 4 or 5 KB of the query image per slab each - and wait for it.  One
+// s_barrier per K slab is the hand-off both ways (slab t landed / slot of slab t - 1 is free).
+__global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restrict__ P, int ldp, int NP, int K,
+                                                          const uint16_t* __restrict__ img, float* __restrict__ out,
+                                                          int ldo, int NQ, int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, qb = blockIdx.y;
+    const int i0 = tile * kRowsP;
+    const int rows = min(kRowsP, NP - i0);
+    // every workgroup walks K from its own starting slab (see sim_split_kernel)
+    const int rot = (int)(((unsigned)tile * 7u) % (unsigned)T);
+
+    if (wave >= 8) {
+        // ================================ loaders ==============================================================
+        const int lw = wave - 8;
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(P + (size_t)i0 * ldp), 0, (int)((((size_t)rows - 1) * ldp + K) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)img + (size_t)qb * T * kSlabQ), 0, T * kSlabQ, 0x00020000);
+        // database piece j = lw * 8 + i covers rows 8j .. 8j+7 (8 lanes x 16 bytes = one 128-byte run per row)
+        uint32_t pvoff[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (lw * 8 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            pvoff[i] = (uint32_t)row * (uint32_t)ldp * 4u + (uint32_t)chunk * 16u;   // rows past `rows`: out of range -> 0
+        }
+        // query image of a slab: 18 pieces of 1 KiB; loaders 0 / 1 take 5, loaders 2 / 3 take 4
+        const int q0 = lw < 2 ? lw * 5 : 10 + (lw - 2) * 4;
+        const bool five = lw < 2;
+        auto issue = [&](int t) __attribute__((always_inline)) {
+            int u = t + rot;
+            u = u >= T ? u - T : u;
+            char* stage = smem + (t % kStages) * kStage;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (!(DIR_SIM_ABL & 1)) dma16s(rsrc_p, stage + (lw * 8 + i) * 1024, pvoff[i], (uint32_t)u * 128u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!(DIR_SIM_ABL & 2))
+                    dma16s(rsrc_q, stage + kSlabP + (q0 + i) * 1024, (uint32_t)((q0 + i) * 1024 + lane * 16), (uint32_t)u * kSlabQ);
+            if (five && !(DIR_SIM_ABL & 2)) dma16s(rsrc_q, stage + kSlabP + (q0 + 4) * 1024, (uint32_t)((q0 + 4) * 1024 + lane * 16), (uint32_t)u * kSlabQ);
+        };
+        issue(0);
+        if (T > 1) issue(1);
+        for (int t = 0; t < T; ++t) {
+            // this wave's part of slab t has landed; its newest 12 / 13 ops (slab t + 1) may stay in flight
+            if (t + 1 < T) {
+                if (five) {
+                    asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();   // hand-off t: slab t is complete; the consumers have left slab t - 1
+            if (t + 2 < T) issue(t + 2);
+        }
+        return;
+    }
+
+    // ==================================== consumers =============================================================
+    const int lrow = lane & 31, lhi = lane >> 5;
+    f32x16_t acc[3], lo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f, lo[j][e] = 0.f;
+    const int boff = (wave * 32 + lrow) * 128, bswz = (lrow >> 1) & 7;
+    const int aoff = kSlabP + lrow * 64, aswz = (lrow >> 2) & 3;
+
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_s_barrier();   // hand-off t (see the loaders)
+        const char* stage = smem + cur * kStage;
+#pragma unroll
+        for (int s = 0; s < ((DIR_SIM_ABL & 4) ? 0 : 2); ++s) {
+            const int c0 = s * 4 + lhi * 2;
+            const f32x4_t b0 = *(const f32x4_t*)(stage + boff + ((c0 ^ bswz) << 4));
+            const f32x4_t b1 = *(const f32x4_t*)(stage + boff + (((c0 + 1) ^ bswz) << 4));
+            u32x4_t ah[3], am[3], al[3];
+            const int ach = ((s * 2 + lhi) ^ aswz) << 4;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ah[j] = *(const u32x4_t*)(stage + aoff + 0 * kPlane + j * 2048 + ach);
+                am[j] = *(const u32x4_t*)(stage + aoff + 1 * kPlane + j * 2048 + ach);
+                al[j] = *(const u32x4_t*)(stage + aoff + 2 * kPlane + j * 2048 + ach);
+            }
+            u32x4_t bh, bm, bl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h, m, l;
+                split2(e < 2 ? b0[2 * e] : b1[2 * e - 4], e < 2 ? b0[2 * e + 1] : b1[2 * e - 3], h, m, l);
+                bh[e] = h, bm[e] = m, bl[e] = l;
+            }
+#define DIR_MM(ACC, A, B)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(         \
+        __builtin_bit_cast(bf16x8_t, A[j]), __builtin_bit_cast(bf16x8_t, B), ACC[j], 0, 0, 0)
+            DIR_MM(lo, al, bh);     // same order of products and accumulators as sim_split_kernel
+            DIR_MM(lo, ah, bl);
+            DIR_MM(lo, am, bm);
+            DIR_MM(lo, am, bh);
+            DIR_MM(lo, ah, bm);
+            DIR_MM(acc, ah, bh);
+#undef DIR_MM
+        }
+        cur = cur + 1 == kStages ? 0 : cur + 1;
+    }
+
+    const int n = i0 + wave * 32 + lrow;
+    if (n < NP) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = qb * kQB + j * 32 + 8 * g + 4 * lhi + e;
+                    if (q < NQ) out[(size_t)q * ldo + n] = acc[j][4 * g + e] + lo[j][4 * g + e];
+                }
+    }
+}
+
 size_t similarity_split_workspace_bytes(int NQ, int K) {
     return (size_t)ceil_div(NQ, kQB) * (size_t)ceil_div(K, 32) * kSlabQ;
 }
@@ -217,12 +356,18 @@ int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* ou
     if (!workspace || workspace_bytes < similarity_split_workspace_bytes(NQ, K))
         return fail(DIR_ERR_WORKSPACE, "similarity_split: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return fail(DIR_ERR_INVALID, "similarity_split: workspace must be 16-byte aligned");
-    static std::atomic<uint64_t> attr_done{0};
+    static std::atomic<uint64_t> attr_done{0}, attr_done_lc{0};
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_kernel, kLds, attr_done));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_lc_kernel, kLds, attr_done_lc));
+    static const bool v1 = getenv("DIRTORCH_AMD_SIM_V1") != nullptr;   // A/B and bisecting: the one-role kernel (read once)
     const int T = K / 32, qblocks = ceil_div(NQ, kQB);
     hipLaunchKernelGGL(split_queries_kernel, dim3(T, qblocks), dim3(256), 0, stream, Q, ldq, NQ, K, (uint16_t*)workspace);
-    hipLaunchKernelGGL(sim_split_kernel, dim3(ceil_div(NP, kRowsP), qblocks), dim3(512), kLds, stream, P, ldp, NP, K,
-                       (const uint16_t*)workspace, out, ldo, NQ, T);
+    if (v1)
+        hipLaunchKernelGGL(sim_split_kernel, dim3(ceil_div(NP, kRowsP), qblocks), dim3(512), kLds, stream, P, ldp, NP, K,
+                           (const uint16_t*)workspace, out, ldo, NQ, T);
+    else
+        hipLaunchKernelGGL(sim_split_lc_kernel, dim3(ceil_div(NP, kRowsP), qblocks), dim3(768), kLds, stream, P, ldp, NP, K,
+                           (const uint16_t*)workspace, out, ldo, NQ, T);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;
 }
