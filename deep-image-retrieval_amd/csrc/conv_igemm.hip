@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        ring_barrier();
         if (issued < T) {
 #ifndef DIR_EXP_NO_FILL     // experiment builds (scripts/exp_fill.sh): MFMA + fragment reads alone
             issue(wstep_now(), tap, koff_now(), smem + slot_i * STAGE_BYTES);

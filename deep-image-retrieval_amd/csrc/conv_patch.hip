@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(NTH) conv_patch3x3_kernel(const ConvArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();  // patch (issued first) and weight stage t have landed
+        ring_barrier();  // patch (issued first) and weight stage t have landed
         if (issued < T) {
             issue_w(issued, slot_i);
             ++issued;
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();      // stage t landed for every wave; slot of stage t - 1 is free
+        ring_barrier();      // stage t landed for every wave; slot of stage t - 1 is free
         if (issued < T) {
             issue_w(issued, slot_i);
             ++issued;
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(512) conv_patch3x3s_kernel(const ConvArgs a) {
                 // the next step's counted wait - which may leave only the newest weight stage outstanding -
                 // cannot be used as is: wait for everything once per plane instead.
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                ring_barrier();
                 issue_plane(kc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(512) conv_patch3x3w_kernel(const ConvArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NBW) : "memory");
         }
-        __builtin_amdgcn_s_barrier();   // stage sigma (and plane q) landed everywhere; everyone is past stage sigma - 1
+        ring_barrier();   // stage sigma (and plane q) landed everywhere; everyone is past stage sigma - 1
         plane_before = false;
         if (r == 0 && q + 1 < NQ) {     // the other plane buffer was last read during plane q - 1
             issue_plane(q + 1);

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                __builtin_amdgcn_s_barrier();  // step t landed everywhere; X slot (t+2)%3 and W slot of t+1 are free
+                ring_barrier();  // step t landed everywhere; X slot (t+2)%3 and W slot of t+1 are free
                 if (t + 1 < T) issue_w(t + 1, wslot(t + 1));
                 if (t + 2 < T) issue_x(t + 2, xslot(t + 2));
                 const char* xs = xslot(t);
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         int issued = 1;
         for (int t = 0; t < T; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // stage t landed everywhere; slot (t+1)&1 is free
+            ring_barrier();  // stage t landed everywhere; slot (t+1)&1 is free
             if (issued < T) {
                 issue(issued, smem + (issued & 1) * STAGE);
                 ++issued;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
             // every wave is done with the staging area (it covers X slot 1).  Raw barrier: __syncthreads()
             // would drain vmcnt, i.e. wait for the stage already in flight and for this tile's stores.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            ring_barrier();
             issue_x(1, xslot(1));
         }
         tile = next;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
 
     for (int i = tid; i < a.Cout; i += 512) lbias[i] = a.bias[i];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the only VGPR-kind loads of the kernel
-    __builtin_amdgcn_s_barrier();
+    ring_barrier();
 
     // Where piece p of the output tile `tile` goes, for the lane that holds (or mirrors) consumer wave cw's lane:
     // piece p = (j, i, h): pixel block j, channel block i, 16-channel half h.  Element offset into y, or -1 past M.
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
 
     if (wave == 7) {
         // the eighth wave only keeps the barrier count (three loaders cover a stage in 16 instructions each)
-        for (int g = 0; g < total; ++g) __builtin_amdgcn_s_barrier();
+        for (int g = 0; g < total; ++g) ring_barrier();
         return;
     }
     if (wave >= 4) {
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();   // hand-off g: stage g is complete; the consumers have left step g - 1
+            ring_barrier();   // hand-off g: stage g is complete; the consumers have left step g - 1
             if (g + 2 < total) issue_next();
         }
         return;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
     f32x16_t acc[TN][TM];
     int tile = first, t = 0, slot = 0;
     for (int g = 0; g < total; ++g) {
-        __builtin_amdgcn_s_barrier();   // hand-off g (see the loaders)
+        ring_barrier();   // hand-off g (see the loaders)
         if (t == 0) {
             const int n_wave = (tile % a.tiles_n) * BN + wn * TN * 32;
 #pragma unroll

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
     u32x4_t rres0[4], rres1[4];
     load_res(tile, 0, rres0);
     store_x(xr, smem);
-    __builtin_amdgcn_s_barrier();   // first tile staged (and the bias table written)
+    ring_barrier();   // first tile staged (and the bias table written)
     for (;;) {
         const bool more = tile + per < mt;
         const int next = more ? tile + per : tile;   // last step: a harmless repeat
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(512) conv1x1_wreg_kernel(const ConvArgs a) {
         store_x(xr, smem + (cur ^ 1) * XBUF);
         tile = next;
         cur ^= 1;
-        __builtin_amdgcn_s_barrier();
+        ring_barrier();
     }
     ovf.flush(a.ovf);
 }

@@ -152,6 +152,26 @@ struct Ovf {
     }
 };
 
+// ---- hand-off barrier of an LDS-DMA ring ------------------------------------------------------------------------------
+// s_barrier with the instruction scheduler fenced on both sides.  hipcc (ROCm 7.2) treats neither
+// `asm volatile("s_waitcnt vmcnt(N)" ::: "memory")` nor the raw s_barrier builtin as a fence for LDS READS when it
+// schedules an unrolled K loop: in conv_patch3x3_kernel<64 channels> it had hoisted the first weight-fragment reads of
+// stage t above the wait + barrier that make stage t visible (ds_read_b128 ... ; s_waitcnt vmcnt(2) ; s_barrier ;
+// buffer_load ... lds ; v_mfma <those registers>).  Harmless while the stage - requested two steps earlier - has
+// always landed by then, i.e. in every single-stream run; with forwards overlapping on several HIP streams about one
+// launch in 2 400 read a half-landed stage (scripts/exp_stream_race_ops.py).  __builtin_amdgcn_sched_barrier(0) is the
+// fence the scheduler honours (CDNA guide, section 5.4 rule 18); tests/test_isa_audit.py checks the emitted code of
+// every ring kernel for LDS reads that cross a barrier into an MFMA.
+__device__ __forceinline__ void ring_barrier() {
+#ifndef DIR_EXP_NO_RING_FENCE   // experiment builds only (scripts/exp_fence.sh): what the two fences cost
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    __builtin_amdgcn_s_barrier();
+#ifndef DIR_EXP_NO_RING_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; give each
 // XCD a contiguous run of logical tiles so neighbouring tiles (which share an operand panel) hit
 // the same 4 MiB L2.  Placement only affects speed, never results.

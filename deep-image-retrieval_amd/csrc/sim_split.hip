@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(512) sim_split_kernel(const float* __restrict_
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kOps) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // slab t landed everywhere; everyone is past slab t-1, whose slot is free
+        ring_barrier();   // slab t landed everywhere; everyone is past slab t-1, whose slot is free
         int nxt = cur + 2;
         if (nxt >= kStages) nxt -= kStages;
         if (t + 2 < T) issue(slab(t + 2), smem + nxt * kStage);
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();   // hand-off t: slab t is complete; the consumers have left slab t - 1
+            ring_barrier();   // hand-off t: slab t is complete; the consumers have left slab t - 1
             if (t + 2 < T) issue(t + 2);
         }
         return;
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
 
     int cur = 0;
     for (int t = 0; t < T; ++t) {
-        __builtin_amdgcn_s_barrier();   // hand-off t (see the loaders)
+        ring_barrier();   // hand-off t (see the loaders)
         const char* stage = smem + cur * kStage;
 #pragma unroll
         for (int s = 0; s < ((DIR_SIM_ABL & 4) ? 0 : 2); ++s) {

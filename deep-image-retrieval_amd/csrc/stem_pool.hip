@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoo
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();   // patch landed everywhere; everyone is done pooling the previous tile
+        ring_barrier();   // patch landed everywhere; everyone is done pooling the previous tile
 
         f32x16_t acc[2][2];   // start at the bias, like every conv kernel of this library (same fp32 order)
 #pragma unroll
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_persist_kernel(const StemPoo
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // conv tile complete; every wave is past its patch reads
+        ring_barrier();   // conv tile complete; every wave is past its patch reads
 
         for (int it = tid; it < PTH * PTW * 8; it += 256) {
             const int c = it & 7;

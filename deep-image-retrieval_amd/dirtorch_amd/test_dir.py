@@ -71,15 +71,14 @@ class StreamPool(object):
     """Round-robin HIP streams for forwards that cannot share a batch (the reference's real workload: batch 1 at
     native resolution, test_dir.py:52-55).  One 1024^2 image gives layers 3 / 4 16-128 workgroups for 256 CUs;
     forwards issued on a few streams overlap on the device (each stream has its own engine workspace,
-    nets/rmac_resnet.py _workspace): 774 -> 1357 img/s at 1024^2 and 834 -> 1728 at 768x1024 with four streams.
-    OPT-IN (DIRTORCH_AMD_STREAMS=n; default 1 = everything on the current stream): with forwards overlapping on
-    several streams about one forward in a few hundred returns a trunk map in which a region differs from the
-    single-stream result by a few fp16 ulps (descriptors: ~1e-6) - scripts/exp_stream_race.py; every kernel alone is
-    bit-reproducible under the same overlap (scripts/exp_stream_race_ops.py) and the cause is not established, so the
-    default keeps the exact, single-stream order of launches."""
+    nets/rmac_resnet.py _workspace): 770 -> 1325 img/s at 1024^2 and 825 -> 1700 at 768x1024 with four streams, the
+    best of 1-6.  DIRTORCH_AMD_STREAMS=n (default 4; 1 = everything on the current stream).
+    Results are bit-identical to the single-stream ones: the same kernels run on the same data, only their
+    interleaving changes (scripts/exp_stream_race.py: 0 of 7 680 forwards differ; that script is also how the one
+    kernel whose emitted code depended on timing was found - csrc/dir_common.h ring_barrier)."""
 
     def __init__(self, n=None):
-        n = int(os.environ.get('DIRTORCH_AMD_STREAMS', '1')) if n is None else n
+        n = int(os.environ.get('DIRTORCH_AMD_STREAMS', '4')) if n is None else n
         self.streams = [torch.cuda.Stream() for _ in range(n)] if n > 1 and torch.cuda.is_available() else []
         self.i = 0
 

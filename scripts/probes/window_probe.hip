@@ -177,6 +177,7 @@ static void run_rows(const char* px, size_t bytes, uint32_t* out, int cus) {
 //   PAT 0: no stores            PAT 1: 4 KB contiguous per step (4 instructions of 1 KB)
 //   PAT 2: full 128-byte lines, 8 rows of 512 B pitch per instruction (what an LDS-staged epilogue emits)
 //   PAT 3: 32 bytes in each of 32 rows of 512 B pitch per instruction (16 B per lane straight from MFMA accumulators)
+//   PAT 4: the same bytes as ONE burst per 16 steps: 64 KB contiguous, 16 instructions from each of waves 4-7
 template <int PAT>
 __global__ void __launch_bounds__(512) rdst_probe(const char* __restrict__ px, size_t px_per_wg, char* __restrict__ out, size_t out_per_wg,
                                                   uint32_t* __restrict__ flag) {
@@ -208,6 +209,15 @@ __global__ void __launch_bounds__(512) rdst_probe(const char* __restrict__ px, s
     char* o = out + (size_t)blockIdx.x * out_per_wg;
     for (int s = 0; s < steps; ++s) {
         __builtin_amdgcn_s_barrier();
+        if (PAT == 4) {
+            if ((s & 15) == 15) {
+                char* tile = o + (size_t)(s >> 4) * 65536;
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    *(__attribute__((address_space(1))) u4*)(tile + (size_t)((wave - 4) * 16 + c) * 1024 + lane * 16) = v;
+            }
+            continue;
+        }
         if (wave != 7 || PAT == 0) continue;
         // the output of the workgroup: tiles of 128 rows x 512 B (64 KB), one tile per 16 steps
         char* tile = o + (size_t)(s >> 4) * 65536;
@@ -238,7 +248,8 @@ static void run_rdst(const char* px, size_t bytes, char* out, uint32_t* flag, in
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    const char* names[] = {"no stores", "contiguous 4 KB per step", "128-B lines, 8 rows per instruction", "32 B in each of 32 rows per instruction"};
+    const char* names[] = {"no stores", "contiguous 4 KB per step", "128-B lines, 8 rows per instruction", "32 B in each of 32 rows per instruction",
+                           "64 KB burst every 16 steps"};
     printf("rd+st   %-40s: %.3f ms  read %.0f GB/s + write %.0f GB/s\n", names[PAT], best, (double)per_wg * cus / best / 1e6,
            PAT ? (double)out_per_wg * cus / best / 1e6 : 0.0);
     hipEventDestroy(e0); hipEventDestroy(e1);
@@ -274,7 +285,7 @@ int main() {
     const int cus = prop.multiProcessorCount;
     char* outb; hipMalloc(&outb, bytes / 4 + (1 << 20));
     for (int rep = 0; rep < 2; ++rep) {
-        run_rdst<0>(a, bytes, outb, out, cus); run_rdst<1>(a, bytes, outb, out, cus); run_rdst<2>(a, bytes, outb, out, cus); run_rdst<3>(a, bytes, outb, out, cus);
+        run_rdst<0>(a, bytes, outb, out, cus); run_rdst<1>(a, bytes, outb, out, cus); run_rdst<2>(a, bytes, outb, out, cus); run_rdst<3>(a, bytes, outb, out, cus); run_rdst<4>(a, bytes, outb, out, cus);
         if (getenv("PROBE_RDST_ONLY")) continue;
         run<0, 1>("px", a, bytes, w, out, cus); run<0, 2>("px", a, bytes, w, out, cus);
         run<0, 3>("px", a, bytes, w, out, cus); run<0, 4>("px", a, bytes, w, out, cus);
