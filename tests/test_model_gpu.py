@@ -97,6 +97,34 @@ def test_batch_composition_is_irrelevant():
         assert float((one - full[i]).abs().max()) < 2e-4, i
 
 
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
+def test_forwards_overlapping_on_streams_are_bit_identical(dtype):
+    """The batch-1 extraction loop issues forwards round-robin on a few HIP streams (test_dir.StreamPool: one 1024^2
+    image cannot fill 256 CUs).  Every trunk map must equal the single-stream one bit for bit - the same kernels run on
+    the same data, only their interleaving changes.  (Round 3 found a kernel whose emitted code read an LDS-DMA stage
+    ahead of its hand-off barrier once per ~2 400 launches under such overlap - csrc/dir_common.h ring_barrier,
+    scripts/exp_stream_race*.py, tests/test_isa_audit.py.  This is the in-suite guard; the scripts have the statistics.)"""
+    import dir_oracle as O
+    from dirtorch_amd.test_dir import StreamPool
+    sd = O.synth_state_dict('resnet50', seed=7)
+    net = make_net('resnet50', {}, sd, dtype)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    imgs = [torch.randint(0, 256, (1, 512, 640, 3), generator=g, dtype=torch.uint8, device='cuda') for _ in range(4)]
+    refs = [net.forward_features(x).clone() for x in imgs]
+    dref = [net(x).clone() for x in imgs]
+    torch.cuda.synchronize()
+    pool = StreamPool(4)
+    assert len(pool.streams) == 4
+    for rep in range(3):
+        outs = [pool.run(lambda x=imgs[i % 4]: net.forward_features(x), imgs[i % 4]) for i in range(64)]
+        descs = [pool.run(lambda x=imgs[i % 4]: net(x), imgs[i % 4]) for i in range(16)]
+        pool.join()
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, refs[i % 4])]
+        assert not bad, 'forwards %s of repetition %d differ from the single-stream trunk map' % (bad[:8], rep)
+        assert all(torch.equal(d, dref[i % 4]) for i, d in enumerate(descs))
+
+
 def test_workspace_and_argument_errors():
     import ctypes
     from dirtorch_amd import _lib
