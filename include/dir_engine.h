@@ -290,7 +290,9 @@ int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mod
  * -1 = unused slot) counts[q][p] = number of database items that rank before it under
  * np.argsort(scores[q])[::-1]: score greater, or equal with a larger index.  probe_scores[q][p]
  * receives scores[q][probe].  scores: [Q][N] fp32 with row stride lds; probe_idx / counts /
- * probe_scores are [Q][P] (any P: the kernel takes 1024 probes per query per launch). */
+ * probe_scores are [Q][P] (any P: 4096 probes per query per pass).  Sorted probes + one binary search per score + a
+ * histogram (ranking.hip): each score is read once per pass, NaN scores rank before nothing, -0 == +0; probe_scores
+ * doubles as the kernels' scratch until the call's last kernel (no workspace argument). */
 int dir_rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P,
                     int* counts, float* probe_scores, void* stream);
 /* N1, second half: the APs themselves on the device - ImageListRelevants.eval_query_AP
