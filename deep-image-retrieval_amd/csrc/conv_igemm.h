@@ -59,12 +59,15 @@ struct ConvVariant {
                                // 5 = LDS-patch 3x3 for wide layers, one 64-channel plane at a time (conv_patch.hip)
                                // 6 = LDS-patch 3x3, 512 pixels x 128 channels, double-buffered 32-channel planes (conv_patchw.hip)
                                // 7 = persistent 128x256 1x1 without a residual, one K ring over all tiles of a workgroup (conv_ring.hip)
+                               // 8 = 64 -> 64 channel 3x3 with the filter resident in LDS, loader / consumer waves (conv_patchlc.hip)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
     ConvLaunchFn launch_dual[2]; // two-source K instantiation (ConvArgs::x2: conv3 + downsample in one GEMM), or nullptr
 };
 
 bool conv1x1_persist_admissible(const ConvArgs& a);
 hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream, bool xdeep = false);
+bool conv_patch64_lc_admissible(const ConvArgs& a);
+hipError_t conv_patch64_lc_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_ring_admissible(const ConvArgs& a);
 hipError_t conv1x1_ring_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_wreg_admissible(const ConvArgs& a);

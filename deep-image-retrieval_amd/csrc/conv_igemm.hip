@@ -503,6 +503,9 @@ static const ConvVariant kVariants[] = {
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
+    // ... 64 -> 64 channels without a residual: the whole filter resident in LDS, double-buffered patches, loader waves
+    // fetch while consumer waves multiply (conv_patchlc.hip)
+    {"256x64_patchlc3x3", 256, 64, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 8, {nullptr, nullptr}, {nullptr, nullptr}},
     // ... for the wide 3x3 layers (256 / 512 channels): the patch one 64-channel plane at a time, Cout tiled by 256
     {"256x256_patch3x3s", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 5, {nullptr, nullptr}, {nullptr, nullptr}},
     // ... 512 pixels x 128 channels per workgroup, 32-channel planes double-buffered, one filter row per weight stage
@@ -532,6 +535,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 4) return conv1x1_persist_admissible(a) && a.res == nullptr;   // the deep-X form has no residual path
     if (cv.kind == 3) return conv1x1_wreg_admissible(a);
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
+    if (cv.kind == 8) return conv_patch64_lc_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
@@ -556,6 +560,14 @@ static int find_variant(const char* name) {
 //     workgroups per CU, so that one's epilogue overlaps the other's K loop;
 // each falling back to smaller pixel tiles until about three quarters of the CU slots get a tile.
 int conv_pick_variant(const ConvArgs& a) {
+    {
+        // layer1's 64 -> 64 3x3: filter resident in LDS, loader / consumer waves (DIRTORCH_AMD_NO_PATCHLC: A/B and bisecting)
+        static const bool no_lc = getenv("DIRTORCH_AMD_NO_PATCHLC") != nullptr;
+        const int v = find_variant("256x64_patchlc3x3");
+        if (!no_lc && v >= 0 && conv_variant_admissible(v, a) &&
+            (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) >= 192)
+            return v;
+    }
     for (int v = 0; v < kNumVariants; ++v)
         if (kVariants[v].kind == 1 && a.Cin == 64 && conv_variant_admissible(v, a)) return v;
     // the residual 1x1 convs with K <= 256 (layer2/3 conv3): weights stationary in registers, as long
@@ -753,6 +765,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
                    : cv.kind == 4 ? conv1x1_persist_launch(a, dtype, stream, true)
                    : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)
                    : cv.kind == 7 ? conv1x1_ring_launch(a, dtype, stream)
+                   : cv.kind == 8 ? conv_patch64_lc_launch(a, dtype, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)

@@ -61,6 +61,9 @@ def short(name):
     m = re.search(r'conv_c3c1_kernel<dir::(\w+), (\d+), (\w+), (\d+)>', name)
     if m:
         return 'conv_c3c1<%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv_patch64_lc_kernel<dir::(\w+)>', name)
+    if m:
+        return 'conv_igemm<256x64_patchlc3x3>[%s]' % m.group(1).lower()
     m = re.search(r'conv1x1_ring_kernel<dir::(\w+)>', name)
     if m:
         return 'conv_igemm<128x256_ring1x1>[%s]' % m.group(1).lower()

@@ -42,6 +42,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
     bn = int(name.split('_')[0].split('x')[1])
     if 'wreg1x1' in name:
         return k == 1 and stride == 1 and pad == 0 and Cout % 512 == 0 and Cin in (128, 256) and has_res
+    if 'patchlc3x3' in name:             # filter resident in LDS, loader / consumer waves: 64 -> 64 without a residual
+        return k == 3 and stride == 1 and pad == 1 and Cin == Cout == 64 and not has_res
     if 'patch3x3w' in name:              # 512 pixels x 128 channels per workgroup, 32-channel planes
         return k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0 and Cin >= 64 and Cout % 128 == 0
     if 'patch3x3s' in name:              # wide layers, one 64-channel plane at a time, Cout tiled by 256
@@ -99,6 +101,8 @@ CONV_SHAPES = [
     ('1x1_s2_ds', 2, 14, 13, 256, 512, 1, 2, 0, False, False),
     ('3x3_multi_tile', 4, 20, 20, 64, 128, 3, 1, 1, True, True),
     ('3x3_patch64_ragged', 2, 13, 37, 64, 64, 3, 1, 1, True, True),
+    ('3x3_patch64_ragged_nores', 3, 21, 45, 64, 64, 3, 1, 1, False, True),   # 3 x 2 tiles per image, ragged both ways, 18 tiles
+    ('3x3_patch64_norelu', 1, 8, 32, 64, 64, 3, 1, 1, False, False),        # exactly one tile
     ('1x1_persist_flat', 2, 24, 27, 256, 512, 1, 1, 0, True, True),
     ('1x1_persist_k128', 1, 40, 40, 128, 256, 1, 1, 0, False, True),
     ('3x3_patch128_exact', 1, 16, 64, 128, 128, 3, 1, 1, False, False),
