@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Where does the 16-bit error of the descriptors come from?  CPU only (the fp32 oracle with selected storage points
+"""(Test tooling, kept beside the tests because it drives the oracle: `python tests/precision_decomposition.py`.)
+Where does the 16-bit error of the descriptors come from?  CPU only (the fp32 oracle with selected storage points
 rounded), on the BatchNorm-calibrated ResNet-50 @ 224^2 case of tests/test_strict_gpu.py.  Storage points of the engine:
   W  the folded conv weights            A  the activations inside a bottleneck (t1, t2, the downsample branch)
   X  the trunk between bottlenecks (the residual carry, stem output included)
