@@ -4,9 +4,10 @@
 // Why it exists.  The north-star tolerance is 1e-4 cosine against the reference's fp32 CPU path
 // (dirtorch/nets/backbones/resnet.py:67-87,157-174).  16-bit storage cannot promise that on a network whose
 // BatchNorm layers cancel a large common mode: on the BatchNorm-calibrated test checkpoint an IDEAL fp16
-// implementation loses 0.9e-4 (ResNet-101 @ 1024^2) / 1.3e-4 (ResNet-50 @ 224^2), half of it from rounding the
-// folded weights, half from rounding the branch activations - an fp32 residual carry changes nothing (DESIGN.md
-// section 4 has the decomposition).  This path removes both: every conv is an implicit GEMM over fp32 NHWC
+// implementation loses 0.9e-4 (ResNet-101 @ 1024^2) / 1.3e-4 (ResNet-50 @ 224^2): rounding the folded WEIGHTS alone
+// costs 6.8e-5 of the latter, the residual carry 5.0e-5, the branch activations 1.8e-5 - an fp32 residual carry would
+// only bring fp16 to 8.5e-5 and does nothing for bf16 (tests/precision_decomposition.py).  This
+// path removes all three: every conv is an implicit GEMM over fp32 NHWC
 // activations and fp32 [Cout][R][S][Cin] weights (eval-mode BatchNorm folded in fp32), bias / residual / ReLU in
 // the epilogue, nothing fused across layers.  The f32 MFMA is a k-ordered fmaf chain, so a conv output differs
 // from the reference's only by summation order (~1e-7 relative).

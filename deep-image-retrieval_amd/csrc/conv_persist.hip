@@ -31,8 +31,9 @@ __device__ __forceinline__ uint32_t fast_div_q(uint32_t n, uint32_t mul, uint32_
 // XDEEP = true : THREE slots for the pixel operand, two for the weights, K-step still 64:
 //     X slots [0,32K) [32K,64K) [64K,96K), W slots [96K,128K) [128K,160K); staging [32K,100K).
 //   The weight half of every stage is an L2 hit, the pixel half comes from HBM: with one 64 KB stage in
-//   flight only 32 KB per CU are HBM requests, and 32 KB / ~2.5 us of loaded latency x 256 CUs is the
-//   3.9 TB/s the 1024 -> 256 convs of layer3 were measured at (profiles/r02_*_kernel_roofline.txt).  Here
+//   flight only 32 KB per CU are HBM requests (round 2 read the 3.9 TB/s of layer3's 1024 -> 256 convs as that
+//   window's limit; round 3's probes put the limit elsewhere - waves that both issue LDS-DMA and multiply
+//   serialise the two, and the layer's read/write mix caps HBM at ~5.2 TB/s: conv_ring.hip).  Here
 //   X runs two K-steps ahead and W one (issue order W(t+1), X(t+2); the wait before step t leaves exactly
 //   X(t+1) - the newest ops, all of the LDS-DMA kind - in flight), so 64-96 KB of HBM requests per CU
 //   are outstanding.  Next tile's W(0) / X(0) still go out before the epilogue, X(1) right after it.
