@@ -422,8 +422,8 @@ int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* 
         return fail(DIR_ERR_INVALID, "conv_dual: tensor exceeds 2^31 bytes; lower the batch");
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv_dual: bad dtype");
     // (small shapes included: the op-level entry point runs the form wherever the tile divides Cout)
-    int variant = -1;
-    for (int v = 0; v < conv_variant_count(); ++v)
+    int variant = conv_pick_dual_variant(a);   // what the engine would run (the ring form where it qualifies or is forced)
+    for (int v = 0; variant < 0 && v < conv_variant_count(); ++v)
         if (conv_variant(v).launch_dual[0] && Cout % conv_variant(v).BN == 0) variant = v;
     if (variant < 0) return fail(DIR_ERR_INVALID, "conv_dual: Cout must be a multiple of 256");
     return conv_launch(a, dtype, variant, (hipStream_t)stream);
