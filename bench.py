@@ -19,6 +19,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 collected inside this process over the timed steps
   cpu_baseline  the CPU oracle (a port of the reference forward) timed on this box's host cores
                 on a bounded sample of the same workload (rank 0, N == 1 only)
+and, inside `config`, `precision`: the fp16 / strict-fp32 rates of the same step and every dtype's distance from the
+CPU oracle (descriptors and mAP), measured outside the timed region.
+
+Two more workloads keep the same flags and JSON contract (the default above is BASELINE configs[1]):
+  --workload distractors   configs[3]: 70 x 1 006 322 x 2048 similarity + device rank / AP, the database sharded over
+                           the ranks, ONE all-gather of descriptor (or --exchange scores: score) blocks
+  --workload multiscale    configs[4]: three scales of resident uint8 1200^2 images, fp16, device-side resize
 """
 import argparse
 import json
