@@ -288,3 +288,63 @@ def test_named_list_datasets_resolve_under_db_root(tmp_path, monkeypatch):
     monkeypatch.delenv('DB_ROOT')
     with pytest.raises(KeyError):
         datasets.create('Landmarks18_pca')
+
+
+def _rank_counts_model(scores, probe):
+    """The arithmetic of csrc/ranking.hip (rank_sort / rank_hist / rank_finalize kernels), restated in NumPy: 64-bit keys
+    (order-preserving image of the score, index), probes sorted by key, one lower bound per score, a histogram, suffix
+    sums scattered back to the probes' slots."""
+    def key(s, idx):
+        s = np.where(s == 0, np.float32(0), s).astype(np.float32)          # -0 -> +0
+        b = s.view(np.uint32).astype(np.uint64)
+        u = np.where(b & 0x80000000, ~b & 0xffffffff, b | 0x80000000)
+        return (u << np.uint64(32)) | idx.astype(np.uint64)
+    Q, P = probe.shape
+    N = scores.shape[1]
+    counts = np.zeros((Q, P), np.int64)
+    KMAX = np.uint64(0xffffffffffffffff)
+    for q in range(Q):
+        valid = probe[q] >= 0
+        ps = np.where(valid, scores[q, np.maximum(probe[q], 0)], np.float32(np.nan))
+        pk = np.where(valid & ~np.isnan(ps), key(np.nan_to_num(ps, nan=0.0), np.maximum(probe[q], 0)), KMAX)
+        order = np.lexsort((np.arange(P), pk))                                # ties between equal keys break on the slot
+        sk = pk[order]
+        ok = ~np.isnan(scores[q])                                             # NaN scores rank before nothing
+        kj = key(np.nan_to_num(scores[q][ok], nan=0.0), np.arange(N)[ok])
+        k = np.searchsorted(sk, kj, side='left')                              # probes with key < key_j
+        hist = np.bincount(k, minlength=P + 1)
+        suffix = np.cumsum(hist[::-1])[::-1]                                  # suffix[i] = sum_{k >= i} hist[k]
+        counts[q, order] = np.where(pk[order] == KMAX, 0, suffix[1:])         # count of sorted position i = sum_{k > i}
+    return counts
+
+
+def test_sorted_probe_rank_counts_equal_the_definition():
+    """The device ranking counts, for every listed image, the items that rank before it under np.argsort(scores)[::-1]
+    (score greater, or equal with a larger index).  ranking.hip does it with sorted probes + a binary search per score +
+    a histogram; this pins that ARITHMETIC (restated in NumPy above) to the definition on the cases the float compare
+    makes delicate: heavy ties, +-0, +-inf, NaN scores and NaN probes, a probe listed twice, unused slots."""
+    r = np.random.RandomState(0)
+    Q, N, P = 4, 3001, 41
+    scores = (r.randint(-4, 5, size=(Q, N)) / 2.0).astype(np.float32)
+    scores[1] = r.standard_normal(N).astype(np.float32)
+    scores[2, ::5] = 0.0
+    scores[2, 1::5] = -0.0
+    scores[3, [3, 77]] = np.nan
+    scores[3, [4, 500]] = [np.inf, -np.inf]
+    probe = np.stack([r.choice(N, P, replace=False) for _ in range(Q)]).astype(np.int32)
+    probe[3, :6] = [3, 77, 4, 500, 4, 2999]
+    probe[0, ::9] = -1
+    want = np.zeros((Q, P), np.int64)
+    j = np.arange(N)
+    for q in range(Q):
+        for k in range(P):
+            p = probe[q, k]
+            if p >= 0:
+                with np.errstate(invalid='ignore'):
+                    want[q, k] = np.count_nonzero((scores[q] > scores[q, p]) | ((scores[q] == scores[q, p]) & (j > p)))
+    assert (_rank_counts_model(scores, probe) == want).all()
+    # and the definition is the reference's order: position in np.argsort(...)[::-1] with ties by descending index
+    order = np.lexsort((np.arange(N), scores[1]))[::-1]
+    rank = np.empty(N, np.int64)
+    rank[order] = np.arange(N)
+    assert (want[1] == rank[probe[1]]).all()
