@@ -146,6 +146,46 @@ int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const
     DIR_CATCH
 }
 
+int dir_conv_bn_act_pair(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                         const void* res_hi, const void* res_lo, void* y_hi, void* y_lo, int B, int H, int W, int Cin,
+                         int Cout, int R, int S, int stride, int pad, int OH, int OW, int relu, void* stream) {
+    DIR_TRY
+    if (!x_hi || !w_hi || !w_lo || !bias || !y_hi) return fail(DIR_ERR_INVALID, "conv_bn_act_pair: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0)
+        return fail(DIR_ERR_INVALID, "conv_bn_act_pair: bad dimension");
+    if (OH != (H + 2 * pad - R) / stride + 1 || OW != (W + 2 * pad - S) / stride + 1 || OH <= 0 || OW <= 0)
+        return fail(DIR_ERR_INVALID, "conv_bn_act_pair: OH/OW do not match the conv geometry");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const uint16_t*)x_hi; a.x_lo = (const uint16_t*)x_lo;
+    a.w = (const uint16_t*)w_hi; a.w_lo = (const uint16_t*)w_lo;
+    a.bias = bias;
+    a.res = (const uint16_t*)res_hi; a.res_lo = (const uint16_t*)res_lo;
+    a.y = (uint16_t*)y_hi; a.y_lo = (uint16_t*)y_lo;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.relu = relu ? 1 : 0;
+    a.M = B * OH * OW;
+    a.Ktot = R * S * Cin;
+    return conv_pair_launch(a, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_prep_input_pair(const void* img, int img_format, const float* mean3, const float* std3, void* out_hi,
+                        void* out_lo, int B, int H, int W, void* stream) {
+    DIR_TRY
+    if (B <= 0 || H <= 0 || W <= 0) return fail(DIR_ERR_INVALID, "prep_input_pair: bad dimension");
+    return prep_input_pair(img, img_format, mean3, std3, out_hi, out_lo, B, H, W, (hipStream_t)stream);
+    DIR_CATCH
+}
+
+int dir_stem_pool_pair(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
+                       void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, void* stream) {
+    DIR_TRY
+    if (B <= 0 || H2 <= 0 || W2 <= 0 || OH <= 0 || OW <= 0) return fail(DIR_ERR_INVALID, "stem_pool_pair: bad dimension");
+    return stem_pool_pair_launch(s2d_hi, s2d_lo, w_hi, w_lo, bias, y_hi, y_lo, B, H2, W2, OH, OW, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_engine_overflow(dir_engine* e, void* stream, int* overflowed) {
     DIR_TRY
     if (!e || !overflowed) return fail(DIR_ERR_INVALID, "overflow: null argument");

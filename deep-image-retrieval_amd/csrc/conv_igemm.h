@@ -34,6 +34,13 @@ struct ConvArgs {
     int H2, W2, stride2;
     uint32_t x2_bytes;
     int* ovf;              // fp16 overflow word (dir_common.h Ovf), or nullptr
+    // paired-fp16 form (conv_pair.hip, DIR_FP16P): every operand is a PAIR of fp16 planes, value = hi + lo with
+    // lo = fp16(v - hi) (~22 significant bits); x / w / res / y above are the hi planes, these the lo planes of the
+    // same layout.  w_lo is required there; x_lo / res_lo / y_lo may be null (single-plane operand / output).
+    const uint16_t* x_lo;
+    const uint16_t* w_lo;
+    const uint16_t* res_lo;
+    uint16_t* y_lo;
     // filled by the launcher
     int tiles_m, tiles_n;
     uint32_t x_bytes, w_bytes;               // buffer-descriptor extents (bounds-checked DMA)
@@ -81,6 +88,11 @@ bool conv_patch3x3w_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3w_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+
+// Paired-fp16 convolution (conv_pair.hip): three fp16 MFMAs per product term (wh.xh + wh.xl + wl.xh) into one fp32
+// accumulator; any R x S <= 4 x 4, stride, padding; Cin % 32 == 0, Cout % 64 == 0.  Returns a dir_status.
+int conv_pair_launch(const ConvArgs& a, hipStream_t stream);
+const char* conv_pair_variant_name(const ConvArgs& a);
 
 int conv_variant_count();
 const ConvVariant& conv_variant(int i);

@@ -24,6 +24,7 @@ struct ConvLayer {
     bool stem = false;    // packed as the 4x4 s1 space-to-depth form (Cin 16)
     uint16_t* d_w = nullptr;
     float* d_wf = nullptr;   // DIR_F32 (strict path, conv_f32.hip): the same layout in fp32; d_w stays null
+    uint16_t* d_w_lo = nullptr;  // DIR_FP16P, the paired layers (stem, layer1; conv_pair.hip): fp16(w - fp16(w)), same layout
     float* d_bias = nullptr;
     // conv3 of a stage's first block whose downsample qualifies (conv_c3c1.hip, DS form): this conv's
     // weights with the downsample's appended along K, and the sum of the two folded-BN biases
@@ -47,6 +48,7 @@ struct ProfSlot {
 
 struct Plan {  // byte offsets into the caller's workspace for one (B, H, W)
     size_t s2d, stem, bufA, bufB, t1, t2, ds, x4, splitk, pooled, fcout, total;
+    size_t lo_s2d, lo_bufA, lo_bufB, lo_t1, lo_t2, lo_ds;   // DIR_FP16P: lo planes of the paired head's tensors
     int H2, W2, OH1, OW1, PH, PW;
 };
 
@@ -56,6 +58,10 @@ struct dir_engine {
     dir_model_desc desc;
     int device = 0;
     int dtype = DIR_BF16;
+    // DIR_FP16P: how many leading blocks (all of layer1 by default) run on fp16 pairs (conv_pair.hip); the stem always does
+    int pair_blocks = 0;
+    // the 16-bit kernels' dtype: DIR_FP16P stores and multiplies fp16 everywhere, pairs of them in the head
+    int kdtype() const { return dtype == DIR_FP16P ? DIR_FP16 : dtype; }
     bool finalized = false;
     std::map<std::string, dir::HostTensor> state;
     std::vector<dir::ConvLayer> convs;
@@ -91,6 +97,14 @@ struct dir_engine {
                      hipStream_t stream);
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
                  int H, int W, int OH, int OW, hipStream_t stream, bool rev_m = false);
+    // DIR_FP16P head (conv_pair.hip): one convolution on fp16 pairs; x_lo / res_lo / y_lo may be null
+    int run_conv_pair(dir::ConvLayer& L, const uint16_t* x, const uint16_t* x_lo, const uint16_t* res,
+                      const uint16_t* res_lo, uint16_t* y, uint16_t* y_lo, int B, int H, int W, int OH, int OW,
+                      hipStream_t stream);
+    // image -> stem -> the first pair_blocks residual blocks, everything a pair of fp16 planes; leaves the last block's
+    // output (hi plane only: what layer2 reads) in *cur and reports the map size and the next block index
+    int forward_pair_head(const void* img, int B, int H, int W, int fmt, char* base, const dir::Plan& p,
+                          hipStream_t stream, uint16_t** cur, int* h, int* w, size_t* next_block);
     // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes
     // do not qualify and nothing was launched
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,

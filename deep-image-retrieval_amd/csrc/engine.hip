@@ -127,13 +127,35 @@ static const HostTensor* find(const std::map<std::string, HostTensor>& st, const
 }
 
 int dir_engine::finalize(int dt) {
-    if (dt != DIR_BF16 && dt != DIR_FP16 && dt != DIR_F32) return fail(DIR_ERR_INVALID, "finalize: bad dtype");
+    if (dt != DIR_BF16 && dt != DIR_FP16 && dt != DIR_F32 && dt != DIR_FP16P)
+        return fail(DIR_ERR_INVALID, "finalize: bad dtype");
     DIR_HIP_CHECK(hipSetDevice(device));
     release();
     dtype = dt;
     auto to16 = [&](float f) { return dt == DIR_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f); };
+    // DIR_FP16P: the stem and the first pair_blocks residual blocks keep their weights as fp16 PAIRS (conv_pair.hip).
+    // Default = all of layer1 (where tests/precision_decomposition.py puts the 16-bit error of a conditioned network);
+    // DIRTORCH_AMD_PAIR_STAGES = 1..4 moves the boundary to the end of that stage.
+    pair_blocks = 0;
+    std::vector<char> is_pair(convs.size(), 0);
+    if (dt == DIR_FP16P) {
+        int stages = 1;
+        if (const char* env = getenv("DIRTORCH_AMD_PAIR_STAGES")) stages = atoi(env);
+        if (stages < 1 || stages > 4) return fail(DIR_ERR_INVALID, "finalize: DIRTORCH_AMD_PAIR_STAGES must be 1..4");
+        for (int s = 0; s < stages; ++s) pair_blocks += desc.layers[s];
+        if (x4_block >= 0 && pair_blocks > x4_block)
+            return fail(DIR_ERR_INVALID, "finalize: the FPN heads keep layer3's output as a single fp16 plane; "
+                                         "DIRTORCH_AMD_PAIR_STAGES must stay below 3 for them");
+        is_pair[0] = 1;
+        for (int bi = 0; bi < pair_blocks; ++bi) {
+            const BlockDef& bd = blocks[bi];
+            for (int ci : {bd.conv1, bd.conv2, bd.conv3, bd.down})
+                if (ci >= 0) is_pair[ci] = 1;
+        }
+    }
 
-    for (ConvLayer& L : convs) {
+    for (size_t li = 0; li < convs.size(); ++li) {
+        ConvLayer& L = convs[li];
         const HostTensor* w = find(state, L.wkey);
         const HostTensor* g = find(state, L.bnprefix + ".weight");
         const HostTensor* bt = find(state, L.bnprefix + ".bias");
@@ -207,6 +229,12 @@ int dir_engine::finalize(int dt) {
         }
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed16.size() * 2));
         DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
+        if (is_pair[li]) {   // lo plane: what the hi plane's rounding left over, itself rounded to fp16
+            std::vector<uint16_t> lo16(packed.size());
+            for (size_t i = 0; i < packed.size(); ++i) lo16[i] = f32_to_f16_bits(packed[i] - f16_bits_to_f32(packed16[i]));
+            DIR_HIP_CHECK(hipMalloc((void**)&L.d_w_lo, lo16.size() * 2));
+            DIR_HIP_CHECK(hipMemcpy(L.d_w_lo, lo16.data(), lo16.size() * 2, hipMemcpyHostToDevice));
+        }
         L.h_w.swap(packed16);
         L.h_bias.swap(bias);
     }
@@ -216,7 +244,7 @@ int dir_engine::finalize(int dt) {
     // materialised: conv_c3c1's DS form (layer1: 64 + 64 channels, stride 1) or the two-source form of the
     // implicit-GEMM kernel (layers 2-4, stride 2).
     for (const BlockDef& bd : blocks) {
-        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0 || dt == DIR_F32) continue;
+        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0 || dt == DIR_F32 || is_pair[bd.conv3]) continue;
         ConvLayer& c3 = convs[bd.conv3];
         const ConvLayer& ds = convs[bd.down];
         if (ds.R != 1 || ds.S != 1 || ds.pad != 0 || ds.Cout != c3.Cout || ds.Cin % 64 != 0 || c3.Cin % 64 != 0) continue;
@@ -273,6 +301,8 @@ void dir_engine::release() {
         if (L.d_w) (void)hipFree(L.d_w);
         if (L.d_wf) (void)hipFree(L.d_wf);
         L.d_wf = nullptr;
+        if (L.d_w_lo) (void)hipFree(L.d_w_lo);
+        L.d_w_lo = nullptr;
         if (L.d_bias) (void)hipFree(L.d_bias);
         if (L.d_w_ds) (void)hipFree(L.d_w_ds);
         if (L.d_bias_ds) (void)hipFree(L.d_bias_ds);
@@ -350,6 +380,33 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->t2 = take(t2 ? t2 : 256);
     p->ds = take(ds ? ds : 256);
     p->x4 = take(x4 ? x4 : 256);
+    p->lo_s2d = p->lo_bufA = p->lo_bufB = p->lo_t1 = p->lo_t2 = p->lo_ds = 0;
+    if (dtype == DIR_FP16P) {   // lo planes of the paired head: image, block outputs, t1 / t2 / downsample of its blocks
+        size_t pio = (size_t)B * p->PH * p->PW * 64 * 2, pt1 = 0, pt2 = 0, pds = 0;
+        int ph = p->PH, pw = p->PW;
+        for (int bi = 0; bi < pair_blocks && bi < (int)blocks.size(); ++bi) {
+            const BlockDef& bd = blocks[bi];
+            const int oh = conv_out(ph, 3, bd.stride, 1), ow = conv_out(pw, 3, bd.stride, 1);
+            const ConvLayer& c1 = convs[bd.conv1];
+            const ConvLayer& cl = convs[desc.bottleneck ? bd.conv3 : bd.conv2];
+            if (desc.bottleneck) {
+                pt1 = std::max(pt1, (size_t)B * ph * pw * c1.Cout * 2);
+                pt2 = std::max(pt2, (size_t)B * oh * ow * convs[bd.conv2].Cout * 2);
+            } else {
+                pt1 = std::max(pt1, (size_t)B * oh * ow * c1.Cout * 2);
+            }
+            if (bd.down >= 0) pds = std::max(pds, (size_t)B * oh * ow * convs[bd.down].Cout * 2);
+            pio = std::max(pio, (size_t)B * oh * ow * cl.Cout * 2);
+            ph = oh;
+            pw = ow;
+        }
+        p->lo_s2d = take((size_t)B * p->H2 * p->W2 * 16 * 2);
+        p->lo_bufA = take(pio);
+        p->lo_bufB = take(pio);
+        p->lo_t1 = take(pt1 ? pt1 : 256);
+        p->lo_t2 = take(pt2 ? pt2 : 256);
+        p->lo_ds = take(pds ? pds : 256);
+    }
     p->splitk = take(kSplitKMaxBytes);   // fp32 partial sums of split-K convs (small-M layers)
     p->pooled = take((size_t)B * head_dim * 4);
     p->fcout = take((size_t)B * std::max(desc.out_dim, head_dim) * 4);
@@ -433,13 +490,13 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
         for (int v = 0; v < conv_variant_count(); ++v) {
             if (!conv_variant_admissible(v, a)) continue;
             a.ksplit = conv_splitk_factor(v, a);
-            int rc = conv_launch(a, dtype, v, stream);  // warm-up (also sets func attributes)
+            int rc = conv_launch(a, kdtype(), v, stream);  // warm-up (also sets func attributes)
             if (rc != DIR_OK) return rc;
             float ms = 1e30f;
             for (int round = 0; round < 2; ++round) {  // best of two timings of 3 launches
                 DIR_HIP_CHECK(hipEventRecord(e0, stream));
                 for (int rep = 0; rep < 3; ++rep) {
-                    rc = conv_launch(a, dtype, v, stream);
+                    rc = conv_launch(a, kdtype(), v, stream);
                     if (rc != DIR_OK) return rc;
                 }
                 DIR_HIP_CHECK(hipEventRecord(e1, stream));
@@ -471,9 +528,130 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
                                     (a.ksplit > 1 ? "/k" + std::to_string(a.ksplit) : "") + ">",
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
-    rc = conv_launch(a, dtype, variant, stream);
+    rc = conv_launch(a, kdtype(), variant, stream);
     if (rc != DIR_OK) return rc;
     return prof_end(stream);
+}
+
+// ---- one convolution on fp16 pairs (DIR_FP16P head, conv_pair.hip) -------------------------------------------------
+int dir_engine::run_conv_pair(ConvLayer& L, const uint16_t* x, const uint16_t* x_lo, const uint16_t* res,
+                              const uint16_t* res_lo, uint16_t* y, uint16_t* y_lo, int B, int H, int W, int OH, int OW,
+                              hipStream_t stream) {
+    if (!L.d_w_lo) return fail(DIR_ERR_STATE, "paired conv on a layer without a lo weight plane: " + L.name);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.x_lo = x_lo;
+    a.w = L.d_w;
+    a.w_lo = L.d_w_lo;
+    a.bias = L.d_bias;
+    a.res = res;
+    a.res_lo = res_lo;
+    a.y = y;
+    a.y_lo = y_lo;
+    a.B = B;
+    a.H = H;
+    a.W = W;
+    a.OH = OH;
+    a.OW = OW;
+    a.Cin = L.Cin;
+    a.Cout = L.Cout;
+    a.R = L.R;
+    a.S = L.S;
+    a.stride = L.stride;
+    a.pad = L.pad;
+    a.relu = L.relu ? 1 : 0;
+    a.ovf = d_ovf;
+    a.M = B * OH * OW;
+    a.Ktot = a.R * a.S * a.Cin;
+    const double macs = (double)a.M * L.Cout * (double)a.Ktot;
+    // every tensor a pair: twice the bytes of the 16-bit form (single-plane operands counted once)
+    const double bytes = 2.0 * ((double)B * H * W * a.Cin * (x_lo ? 2 : 1) + (double)a.M * L.Cout * (y_lo ? 2 : 1) +
+                                (double)a.M * L.Cout * (res ? (res_lo ? 2 : 1) : 0) + 2.0 * L.Cout * a.Ktot);
+    int rc = DIR_OK;
+    if (profiling && !prof_paused)
+        rc = prof_begin(L.name, std::string("conv_pair<") + conv_pair_variant_name(a) + ">", 2.0 * macs, bytes, stream);
+    if (rc != DIR_OK) return rc;
+    rc = conv_pair_launch(a, stream);
+    if (rc != DIR_OK) return rc;
+    return prof_end(stream);
+}
+
+// ---- DIR_FP16P: image -> stem -> the paired residual blocks ---------------------------------------------------------
+// The reference's op sequence (ResNet.forward resnet.py:157-161, Bottleneck.forward :67-87 / BasicBlock :29-44), nothing
+// fused across layers; every tensor two fp16 planes (hi in the ordinary workspace regions, lo in the lo_* regions).
+int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt, char* base, const Plan& p,
+                                  hipStream_t stream, uint16_t** cur_out, int* h_out, int* w_out, size_t* next_block) {
+    uint16_t* s2d = (uint16_t*)(base + p.s2d);
+    uint16_t* s2d_lo = (uint16_t*)(base + p.lo_s2d);
+    uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
+    uint16_t* const pl[2] = {(uint16_t*)(base + p.lo_bufA), (uint16_t*)(base + p.lo_bufB)};
+    uint16_t* t1 = (uint16_t*)(base + p.t1);
+    uint16_t* t2 = (uint16_t*)(base + p.t2);
+    uint16_t* ds = (uint16_t*)(base + p.ds);
+    uint16_t* t1_lo = (uint16_t*)(base + p.lo_t1);
+    uint16_t* t2_lo = (uint16_t*)(base + p.lo_t2);
+    uint16_t* ds_lo = (uint16_t*)(base + p.lo_ds);
+    int rc;
+    if (img) {
+        rc = prof_begin("prep_input", "prep_input_pair", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
+                        (double)B * p.H2 * p.W2 * 64, stream);
+        if (rc != DIR_OK) return rc;
+        rc = prep_input_pair(img, fmt, desc.mean, desc.std, s2d, s2d_lo, B, H, W, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    } else {   // autotune: synthetic noise (the paired kernels themselves have nothing to tune)
+        const long n = (long)B * p.H2 * p.W2 * 16;
+        hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s2d, n, DIR_FP16);
+        DIR_HIP_CHECK(hipGetLastError());
+        DIR_HIP_CHECK(hipMemsetAsync(s2d_lo, 0, (size_t)n * 2, stream));
+    }
+    int cur = 0;
+    rc = prof_begin("conv1+maxpool", "stem_pool_pair", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
+                    4.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256), stream);
+    if (rc != DIR_OK) return rc;
+    rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, pp[cur], pl[cur], B, p.H2, p.W2,
+                               p.OH1, p.OW1, stream, d_ovf);
+    if (rc != DIR_OK) return rc;
+    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+
+    int h = p.PH, w = p.PW;
+    const size_t nb = std::min((size_t)pair_blocks, blocks.size());
+    for (size_t bi = 0; bi < nb; ++bi) {
+        BlockDef& bd = blocks[bi];
+        const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
+        const int nxt = cur ^ 1;
+        // the block after the paired region reads single fp16 planes: the last paired block writes its hi plane only
+        uint16_t* out_lo = bi + 1 < nb ? pl[nxt] : nullptr;
+        const uint16_t *resid = pp[cur], *resid_lo = pl[cur];
+        if (bd.down >= 0) {
+            rc = run_conv_pair(convs[bd.down], pp[cur], pl[cur], nullptr, nullptr, ds, ds_lo, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            resid = ds;
+            resid_lo = ds_lo;
+        }
+        if (desc.bottleneck) {
+            rc = run_conv_pair(convs[bd.conv1], pp[cur], pl[cur], nullptr, nullptr, t1, t1_lo, B, h, w, h, w, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_pair(convs[bd.conv2], t1, t1_lo, nullptr, nullptr, t2, t2_lo, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_pair(convs[bd.conv3], t2, t2_lo, resid, resid_lo, pp[nxt], out_lo, B, oh, ow, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+        } else {
+            rc = run_conv_pair(convs[bd.conv1], pp[cur], pl[cur], nullptr, nullptr, t1, t1_lo, B, h, w, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+            rc = run_conv_pair(convs[bd.conv2], t1, t1_lo, resid, resid_lo, pp[nxt], out_lo, B, oh, ow, oh, ow, stream);
+            if (rc != DIR_OK) return rc;
+        }
+        cur = nxt;
+        h = oh;
+        w = ow;
+    }
+    *cur_out = pp[cur];
+    *h_out = h;
+    *w_out = w;
+    *next_block = nb;
+    return DIR_OK;
 }
 
 // ---- fused bottleneck seam ----------------------------------------------------------------------------
@@ -535,7 +713,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
                         "conv_c3c1<" + std::to_string(c3.Cin) + (block_in ? ",ds>" : ">"),
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
-    hipError_t e = conv_c3c1_launch(a, dtype, stream);
+    hipError_t e = conv_c3c1_launch(a, kdtype(), stream);
     if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv_c3c1 launch: ") + hipGetErrorString(e));
     *used = 1;
     return prof_end(stream);
@@ -581,7 +759,7 @@ int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t
         rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".ds+conv3",
                         std::string("conv_igemm<") + conv_variant(variant).name + "/dual>", 2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
-    rc = conv_launch(a, dtype, variant, stream);
+    rc = conv_launch(a, kdtype(), variant, stream);
     if (rc != DIR_OK) return rc;
     return prof_end(stream);
 }
@@ -627,48 +805,59 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     float* pooled = (float*)(base + p.pooled);
     float* fcout = (float*)(base + p.fcout);
 
-    // 1. image -> space-to-depth NHWC16
-    if (img) {
-        rc = prof_begin("prep_input", "prep_input", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
-                        (double)B * p.H2 * p.W2 * 32, stream);
+    const int kd = kdtype();
+    int h = 0, w = 0;
+    size_t first_block = 0;
+    if (dtype == DIR_FP16P) {
+        // 1-2'. paired head: image, stem and the first pair_blocks residual blocks on fp16 pairs (conv_pair.hip)
+        rc = forward_pair_head(img, B, H, W, fmt, base, p, stream, &cur, &h, &w, &first_block);
         if (rc != DIR_OK) return rc;
-        rc = prep_input(img, fmt, desc.mean, desc.std, s2d, B, H, W, dtype, stream);
-        if (rc != DIR_OK) return rc;
-        if ((rc = prof_end(stream)) != DIR_OK) return rc;
-    } else {  // autotune: synthetic noise straight into the s2d buffer
-        const long n = (long)B * p.H2 * p.W2 * 16;
-        hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           s2d, n, dtype);
-        DIR_HIP_CHECK(hipGetLastError());
-    }
-    // 2. stem + maxpool: one kernel (stem_pool.hip) unless DIRTORCH_AMD_UNFUSED_STEM=1
-    static const bool unfused_stem = getenv("DIRTORCH_AMD_UNFUSED_STEM") != nullptr;
-    if (unfused_stem) {
-        rc = run_conv(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
-        if (rc != DIR_OK) return rc;
-        rc = prof_begin("maxpool", "maxpool_3x3s2", 0,
-                        2.0 * ((double)B * p.OH1 * p.OW1 * 64 + (double)B * p.PH * p.PW * 64), stream);
-        if (rc != DIR_OK) return rc;
-        rc = maxpool_3x3s2(stem, cur, B, p.OH1, p.OW1, 64, dtype, stream);
-        if (rc != DIR_OK) return rc;
-        if ((rc = prof_end(stream)) != DIR_OK) return rc;
     } else {
-        rc = prof_begin("conv1+maxpool", "stem_pool", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
-                        2.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256),
-                        stream);
-        if (rc != DIR_OK) return rc;
-        rc = stem_pool_launch(s2d, convs[0].d_w, convs[0].d_bias, cur, B, p.H2, p.W2, p.OH1, p.OW1,
-                              dtype, stream, d_ovf);
-        if (rc != DIR_OK) return rc;
-        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        // 1. image -> space-to-depth NHWC16
+        if (img) {
+            rc = prof_begin("prep_input", "prep_input", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
+                            (double)B * p.H2 * p.W2 * 32, stream);
+            if (rc != DIR_OK) return rc;
+            rc = prep_input(img, fmt, desc.mean, desc.std, s2d, B, H, W, kd, stream);
+            if (rc != DIR_OK) return rc;
+            if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        } else {  // autotune: synthetic noise straight into the s2d buffer
+            const long n = (long)B * p.H2 * p.W2 * 16;
+            hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                               s2d, n, kd);
+            DIR_HIP_CHECK(hipGetLastError());
+        }
+        // 2. stem + maxpool: one kernel (stem_pool.hip) unless DIRTORCH_AMD_UNFUSED_STEM=1
+        static const bool unfused_stem = getenv("DIRTORCH_AMD_UNFUSED_STEM") != nullptr;
+        if (unfused_stem) {
+            rc = run_conv(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
+            if (rc != DIR_OK) return rc;
+            rc = prof_begin("maxpool", "maxpool_3x3s2", 0,
+                            2.0 * ((double)B * p.OH1 * p.OW1 * 64 + (double)B * p.PH * p.PW * 64), stream);
+            if (rc != DIR_OK) return rc;
+            rc = maxpool_3x3s2(stem, cur, B, p.OH1, p.OW1, 64, kd, stream);
+            if (rc != DIR_OK) return rc;
+            if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        } else {
+            rc = prof_begin("conv1+maxpool", "stem_pool", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
+                            2.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256),
+                            stream);
+            if (rc != DIR_OK) return rc;
+            rc = stem_pool_launch(s2d, convs[0].d_w, convs[0].d_bias, cur, B, p.H2, p.W2, p.OH1, p.OW1,
+                                  kd, stream, d_ovf);
+            if (rc != DIR_OK) return rc;
+            if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        }
+        h = p.PH;
+        w = p.PW;
     }
 
     // 3. residual stages (two ping-pong buffers; the FPN heads park layer3's output in its own buffer)
     uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
     uint16_t* x4 = nullptr;
-    int h = p.PH, w = p.PW, h4 = 0, w4 = 0;
+    int h4 = 0, w4 = 0;
     bool t1_ready = false;
-    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+    for (size_t bi = first_block; bi < blocks.size(); ++bi) {
         BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
         const bool keep = (int)bi == x4_block;
@@ -763,7 +952,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             rc = prof_begin("x4+up(c5)", "upsample_add", 0,
                             2.0 * ((double)B * h4 * w4 * x4_dim * 2 + (double)B * h * w * x4_dim), stream);
             if (rc != DIR_OK) return rc;
-            rc = upsample_add(x4, t1, sum, B, h4, w4, h, w, x4_dim, dtype, stream, d_ovf);
+            rc = upsample_add(x4, t1, sum, B, h4, w4, h, w, x4_dim, kd, stream, d_ovf);
             if (rc != DIR_OK) return rc;
             if ((rc = prof_end(stream)) != DIR_OK) return rc;
             rc = run_conv(convs[conv3c4], sum, nullptr, t2, B, h4, w4, h4, w4, stream);
@@ -773,7 +962,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         rc = prof_begin("adpoolc4", "global_pool", 0, (double)B * h4 * w4 * x4_dim * 2, stream);
         if (rc != DIR_OK) return rc;
         rc = global_pool(c4, pooled, head_dim, B, h4, w4, x4_dim, DIR_POOL_GEM, gem_p4, 1e-6f, 0.f,
-                         dtype, stream);
+                         kd, stream);
         if (rc != DIR_OK) return rc;
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
     }
@@ -783,7 +972,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     // the FPN forward never applies center_bias (rmac_resnet_fpn.py:50-86), the classifier averages
     rc = global_pool(cur, pooled + (fpn ? x4_dim : 0), head_dim, B, h, w, feat_dim,
                      classifier ? DIR_POOL_AVG : desc.pooling, gem_p, 1e-6f,
-                     (fpn || classifier) ? 0.f : desc.center_bias, dtype, stream);
+                     (fpn || classifier) ? 0.f : desc.center_bias, kd, stream);
     if (rc != DIR_OK) return rc;
     if ((rc = prof_end(stream)) != DIR_OK) return rc;
     if (desc.norm_features && !classifier) {

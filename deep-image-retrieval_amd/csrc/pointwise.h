@@ -20,6 +20,12 @@ int multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, f
                     hipStream_t stream);
 int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y, int B, int H2, int W2,
                      int OH, int OW, int dtype, hipStream_t stream, int* ovf = nullptr);
+// the paired-fp16 forms of prep_input and of the stem (conv_pair.hip, DIR_FP16P): every tensor is two fp16 planes
+int prep_input_pair(const void* img, int fmt, const float* mean3, const float* std3, void* out_hi, void* out_lo, int B,
+                    int H, int W, hipStream_t stream);
+int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
+                          void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream,
+                          int* ovf = nullptr);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
 int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* pscores, const int* pos_off,

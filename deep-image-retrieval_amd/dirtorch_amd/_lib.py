@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DIRTORCH_AMD_LIB: an alternative build of the same library (kernel experiments); no other effect
 LIB_PATH = os.environ.get('DIRTORCH_AMD_LIB') or os.path.join(_HERE, 'libdir_engine.so')
 
-DIR_BF16, DIR_FP16, DIR_F32 = 0, 1, 2
+DIR_BF16, DIR_FP16, DIR_F32, DIR_FP16P = 0, 1, 2, 3
 DIR_ERR_RANGE = -7      # dir_status: a finite fp32 weight does not fit the chosen 16-bit format
-DTYPES = {'bf16': DIR_BF16, 'fp16': DIR_FP16, 'f32': DIR_F32}
+DTYPES = {'bf16': DIR_BF16, 'fp16': DIR_FP16, 'f32': DIR_F32, 'fp16p': DIR_FP16P}
 DIR_IMG_F32_NCHW, DIR_IMG_U8_NHWC = 0, 1
 DIR_POOL_GEM, DIR_POOL_MAX, DIR_POOL_AVG = 0, 1, 2
 POOLING = {'gem': DIR_POOL_GEM, 'max': DIR_POOL_MAX, 'avg': DIR_POOL_AVG}
@@ -67,6 +67,10 @@ SIGNATURES = {
     'dir_conv_bn_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14
                         + [c_void_p]),
     'dir_conv_bn_act_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    'dir_conv_bn_act_pair': (c_int, [c_void_p] * 4 + [c_void_p] + [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
+    'dir_prep_input_pair': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_void_p]),
+    'dir_stem_pool_pair': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     'dir_engine_overflow': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'dir_conv_heuristic': (c_int, [c_int] * 12 + [c_char_p, c_int, POINTER(c_int)]),
     'dir_conv_bn_act_splitk': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 15 +

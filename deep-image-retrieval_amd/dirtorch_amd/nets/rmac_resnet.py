@@ -37,12 +37,17 @@ def _default_dtype():
       bf16  BASELINE configs[1], bench.py's headline dtype: fp32's range, 8-bit mantissa (7e-4 ... 3.5e-3
             on the calibrated checkpoint - it cannot meet 1e-4 there, whatever the kernels do).
       f32   STRICT: the reference's own arithmetic (fp32 storage, fp32 matrix cores, conv_f32.hip), 1e-7
-            class agreement with the fp32 CPU path at about 1/8 of the 16-bit throughput."""
+            class agreement with the fp32 CPU path at about 1/8 of the 16-bit throughput.
+      fp16p fp16 with a PAIRED head: the image, the stem and layer1 - where a conditioned network makes ~94 % of its
+            16-bit rounding error (tests/precision_decomposition.py) - run on pairs of fp16 values (hi + lo, ~22 bits,
+            three MFMAs per product: conv_pair.hip), layers 2-4 on the fp16 kernels.  Under 1e-5 of descriptor cosine
+            on the calibrated checkpoint (the 1e-4 bar with a 10x margin) at about 3/4 of the fp16 throughput.
+            DIRTORCH_AMD_PAIR_STAGES=2..4 (read when the engine is built) extends the paired region."""
     name = os.environ.get('DIRTORCH_AMD_DTYPE', 'fp16').lower()
     if name in ('fp32', 'strict'):
         name = 'f32'
     if name not in _lib.DTYPES:
-        raise ValueError("DIRTORCH_AMD_DTYPE must be 'bf16', 'fp16' or 'f32'")
+        raise ValueError("DIRTORCH_AMD_DTYPE must be 'bf16', 'fp16', 'fp16p' or 'f32'")
     return name
 
 
@@ -214,7 +219,7 @@ class ResNet_RMAC(object):
             call('dir_engine_set_tensor', self._engine, k.encode(), ctypes.c_void_p(t.data_ptr()),
                  shape, t.dim())
         if self.compute_dtype not in _lib.DTYPES:
-            raise ValueError("compute_dtype must be 'bf16', 'fp16' or 'f32', not %r" % (self.compute_dtype,))
+            raise ValueError("compute_dtype must be 'bf16', 'fp16', 'fp16p' or 'f32', not %r" % (self.compute_dtype,))
         try:
             call('dir_engine_finalize', self._engine, _lib.DTYPES[self.compute_dtype])
         except _lib.DirError as e:
@@ -330,7 +335,8 @@ class ResNet_RMAC(object):
         for _ in range(3):
             h = (h - 1) // 2 + 1
             w = (w - 1) // 2 + 1
-        dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'f32': torch.float32}[self.compute_dtype]
+        dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp16p': torch.float16,
+              'f32': torch.float32}[self.compute_dtype]
         feat = torch.empty(B, h, w, self.trunk_dim, dtype=dt, device=x.device)
         oh, ow, oc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         call('dir_forward_features', self._engine, ptr(x), B, H, W, fmt, ptr(feat),

@@ -329,3 +329,70 @@ def stem_pool(s2d, w_packed, bias, out_hw):
     call('dir_stem_pool', ptr(s2d), ptr(w_packed), ptr(bias), ptr(y), B, H2, W2, OH, OW,
          _dtype_code(s2d), stream_ptr())
     return y
+
+
+# ---- the paired-fp16 head of DIR_FP16P (csrc/conv_pair.hip) ----------------------------------------------------------
+def split_pair(t):
+    """fp32 tensor -> (hi, lo) fp16 planes with hi = fp16(t), lo = fp16(t - hi): the storage format of the paired
+    head (device-side torch casts: test tooling for operands, the kernels produce their own pairs)."""
+    hi = t.to(torch.float16)
+    return hi, (t - hi.to(torch.float32)).to(torch.float16)
+
+
+def conv_bn_act_pair(x, w, bias, res=None, stride=1, pad=0, relu=True, pair_out=True):
+    """dir_conv_bn_act_pair.  x = (hi, lo) or a single fp16 tensor, NHWC [B,H,W,Cin]; w = (hi, lo) [Cout,R,S,Cin];
+    res = None, a single fp16 tensor or (hi, lo).  Returns (y_hi, y_lo), y_lo None when pair_out is False."""
+    x_hi, x_lo = x if isinstance(x, (tuple, list)) else (x, None)
+    w_hi, w_lo = w
+    r_hi, r_lo = (res if isinstance(res, (tuple, list)) else (res, None))
+    _need_cuda(x_hi, x_lo, w_hi, w_lo, bias, r_hi, r_lo)
+    for t in (x_hi, x_lo, w_hi, w_lo, r_hi, r_lo):
+        if t is not None and t.dtype != torch.float16:
+            raise TypeError('fp16 planes expected')
+    B, H, W, Cin = x_hi.shape
+    Cout, R, S, Cin2 = w_hi.shape
+    if Cin2 != Cin:
+        raise ValueError('Cin mismatch')
+    OH = (H + 2 * pad - R) // stride + 1
+    OW = (W + 2 * pad - S) // stride + 1
+    y_hi = torch.empty(B, OH, OW, Cout, dtype=torch.float16, device=x_hi.device)
+    y_lo = torch.empty_like(y_hi) if pair_out else None
+    call('dir_conv_bn_act_pair', ptr(x_hi), ptr(x_lo), ptr(w_hi), ptr(w_lo), ptr(bias), ptr(r_hi), ptr(r_lo),
+         ptr(y_hi), ptr(y_lo), B, H, W, Cin, Cout, R, S, stride, pad, OH, OW, int(bool(relu)), stream_ptr())
+    return y_hi, y_lo
+
+
+def prep_input_pair(img, mean=None, std=None):
+    """fp32 NCHW (normalised) or uint8 NHWC image batch -> space-to-depth NHWC16 stem input as an fp16 pair."""
+    _need_cuda(img)
+    if img.dtype == torch.float32:
+        B, C, H, W = img.shape
+        fmt = _lib.DIR_IMG_F32_NCHW
+    elif img.dtype == torch.uint8:
+        B, H, W, C = img.shape
+        fmt = _lib.DIR_IMG_U8_NHWC
+    else:
+        raise TypeError('image must be float32 NCHW or uint8 NHWC')
+    if C != 3:
+        raise ValueError('3-channel image expected')
+    hi = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 16, dtype=torch.float16, device=img.device)
+    lo = torch.empty_like(hi)
+    m = (ctypes.c_float * 3)(*(mean or (0, 0, 0)))
+    s = (ctypes.c_float * 3)(*(std or (1, 1, 1)))
+    call('dir_prep_input_pair', ptr(img), fmt, m, s, ptr(hi), ptr(lo), B, H, W, stream_ptr())
+    return hi, lo
+
+
+def stem_pool_pair(s2d, w_packed, bias, out_hw):
+    """dir_stem_pool_pair: s2d = (hi, lo) [B,H2,W2,16], w_packed = (hi, lo) [64,4,4,16] (pack_stem_weight of the
+    fp32 filter, then split_pair), out_hw = conv output size -> pooled (hi, lo) [B,PH,PW,64]."""
+    (s_hi, s_lo), (w_hi, w_lo) = s2d, w_packed
+    _need_cuda(s_hi, s_lo, w_hi, w_lo, bias)
+    B, H2, W2, _ = s_hi.shape
+    OH, OW = out_hw
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    y_hi = torch.empty(B, PH, PW, 64, dtype=torch.float16, device=s_hi.device)
+    y_lo = torch.empty_like(y_hi)
+    call('dir_stem_pool_pair', ptr(s_hi), ptr(s_lo), ptr(w_hi), ptr(w_lo), ptr(bias), ptr(y_hi), ptr(y_lo), B, H2, W2,
+         OH, OW, stream_ptr())
+    return y_hi, y_lo

@@ -13,8 +13,8 @@
  *   - all tensor pointers are DEVICE pointers owned by the caller unless the name says host_;
  *     `stream` is a hipStream_t passed as void* (NULL = the default stream).  Nothing here
  *     synchronises the device except dir_engine_finalize and the profiling getters.
- *   - activations are NHWC, 16-bit (bf16 or fp16) or fp32 (DIR_F32, the strict path), chosen at finalize;
- *     accumulation is always fp32.
+ *   - activations are NHWC, 16-bit (bf16 or fp16; DIR_FP16P: pairs of fp16 planes in the stem and layer1) or fp32
+ *     (DIR_F32, the strict path), chosen at finalize; accumulation is always fp32.
  *   - the engine owns only its packed weights; the caller owns images, descriptors and workspace.
  *   - a handle is not re-entrant: one handle per device, one calling thread at a time
  *     (the reference calls net(x) from one thread, dirtorch/test_dir.py:67-81).
@@ -46,8 +46,14 @@ typedef enum dir_status {
 typedef enum dir_dtype {
     DIR_BF16 = 0,             /* bf16 storage, bf16 MFMA: fp32's exponent range, 8-bit mantissa               */
     DIR_FP16 = 1,             /* fp16 storage, fp16 MFMA: 11-bit mantissa, saturates at 65504 (dir_engine_overflow) */
-    DIR_F32 = 2               /* STRICT: fp32 storage and products on the fp32 matrix cores (conv_f32.hip) - the
+    DIR_F32 = 2,              /* STRICT: fp32 storage and products on the fp32 matrix cores (conv_f32.hip) - the
                                  reference's own arithmetic up to summation order; ~1/8 of the 16-bit throughput */
+    DIR_FP16P = 3             /* fp16 with a PAIRED head: the image, the stem and layer1 - where a conditioned network
+                                 makes ~94 % of its 16-bit rounding error - are stored as pairs of fp16 planes
+                                 (v ~ hi + lo, ~22 bits) and multiplied with three fp16 MFMAs per term (conv_pair.hip);
+                                 layers 2-4 are DIR_FP16.  Meets the 1e-4 cosine bar on BatchNorm-calibrated
+                                 checkpoints at ~3/4 of the fp16 throughput.  DIRTORCH_AMD_PAIR_STAGES=1..4 (read at
+                                 finalize) extends the paired region to later stages. */
 } dir_dtype;
 
 typedef enum dir_img_format {
@@ -123,6 +129,23 @@ int dir_forward_features(dir_engine* e, const void* img, int B, int H, int W, in
 int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H,
                         int W, int Cin, int Cout, int R, int S, int stride, int pad, int OH, int OW, int relu,
                         void* stream);
+/* The paired-fp16 head of DIR_FP16P (csrc/conv_pair.hip).  Every operand is a PAIR of fp16 planes of the ordinary
+ * layout, value = hi + lo with hi = fp16(v), lo = fp16(v - hi) (~22 significant bits); every product runs as three fp16
+ * MFMAs into one fp32 accumulator (w_hi.x_hi + w_hi.x_lo + w_lo.x_hi).  Replaces, at ~fp32 accuracy,
+ *   dir_conv_bn_act_pair  Conv2d + eval BatchNorm (+ residual add) (+ ReLU), dirtorch/nets/backbones/resnet.py:56-63,
+ *                         70-85: x [B,H,W,Cin], w [Cout][R][S][Cin], res / y [B,OH,OW,Cout]; Cin % 32 == 0,
+ *                         Cout % 64 == 0, R, S <= 4; x_lo / res_lo / y_lo may be NULL (single-plane operand / output)
+ *   dir_prep_input_pair   ToTensor + Normalize (dirtorch/utils/transforms.py:617-623) -> space-to-depth pair
+ *                         [B, ceil(H/2), ceil(W/2), 16] x 2
+ *   dir_stem_pool_pair    conv 7x7 s2 + BN + ReLU + MaxPool 3x3 s2 (resnet.py:115-119) from that pair and the 4x4x16
+ *                         packed filter pair to the pooled pair [B,PH,PW,64] x 2; the conv tile stays fp32 in LDS. */
+int dir_conv_bn_act_pair(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                         const void* res_hi, const void* res_lo, void* y_hi, void* y_lo, int B, int H, int W, int Cin,
+                         int Cout, int R, int S, int stride, int pad, int OH, int OW, int relu, void* stream);
+int dir_prep_input_pair(const void* img, int img_format, const float* mean3, const float* std3, void* out_hi,
+                        void* out_lo, int B, int H, int W, void* stream);
+int dir_stem_pool_pair(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
+                       void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, void* stream);
 /* fp16 range check.  The reference computes in fp32 and cannot overflow (dirtorch/nets/backbones/resnet.py:67-87);
  * DIR_FP16 storage saturates at 65504.  Every kernel that packs fp32 sums into fp16 for a store ORs into an
  * engine-owned device word when it stores an inf / NaN - the first overflow of a forward is always such a store,

@@ -50,6 +50,11 @@ from synth import (ARCH, BN_EPS, conv_specs, synth_state_dict, synth_images,  # 
 def _q(t, quant):
     if quant is None:
         return t
+    if quant == 'fp16p' or isinstance(quant, tuple):   # outside the paired head DIR_FP16P is fp16
+        quant = 'fp16'
+    if quant == 'pair':   # the paired head of DIR_FP16P (csrc/conv_pair.hip): v ~ fp16(v) + fp16(v - fp16(v))
+        hi = t.to(torch.float16).to(torch.float32)
+        return hi + (t - hi).to(torch.float16).to(torch.float32)
     dt = {'bf16': torch.bfloat16, 'fp16': torch.float16}[quant]
     return t.to(dt).to(torch.float32)
 
@@ -77,6 +82,12 @@ def resnet_features(sd, arch, x, quant=None, with_x4=False):
     """ResNet.forward up to layer4 (fc_out == 0 for *_rmac): [B,3,H,W] -> [B,C,h,w] fp32.
     with_x4 = the out_layer == -1 form (resnet.py:166-167): returns (layer3 map, layer4 map)."""
     bottleneck, layers = ARCH[arch]
+    # quant = 'fp16p' (DIR_FP16P): image, stem and the first `pair_stages` stages keep fp16 PAIRS (~22 bits), the last
+    # paired block hands a single fp16 plane to the rest of the trunk, which is 'fp16'
+    fp16p = quant == 'fp16p' or (isinstance(quant, tuple) and quant[0] == 'fp16p')
+    pair_stages = (quant[1] if isinstance(quant, tuple) else 1) if fp16p else 0
+    tail_quant = 'fp16' if fp16p else quant
+    quant = 'pair' if fp16p else quant
     x = _q(x.float(), quant)
     x = _q(F.relu(_conv_bn(sd, x, 'conv1.weight', 'bn1', 2, 3, quant)), quant)
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
@@ -84,6 +95,8 @@ def resnet_features(sd, arch, x, quant=None, with_x4=False):
     exp = 4 if bottleneck else 1
     for s, planes in enumerate((64, 128, 256, 512)):
         for j in range(layers[s]):
+            if fp16p and s >= pair_stages:
+                quant = tail_quant
             pre = 'layer%d.%d' % (s + 1, j)
             stride = 2 if (j == 0 and s > 0) else 1
             residual = x
@@ -97,7 +110,8 @@ def resnet_features(sd, arch, x, quant=None, with_x4=False):
             if j == 0 and (stride != 1 or inplanes != planes * exp):
                 residual = _q(_conv_bn(sd, x, pre + '.downsample.0.weight', pre + '.downsample.1',
                                        stride, 0, quant), quant)
-            x = _q(F.relu(out + residual), quant)
+            last_pair = fp16p and s == pair_stages - 1 and j == layers[s] - 1   # what the fp16 tail reads
+            x = _q(F.relu(out + residual), tail_quant if last_pair else quant)
             inplanes = planes * exp
         if s == 2:
             x4 = x

@@ -55,6 +55,9 @@ def short(name):
                                                           '/splitk' if sk == 'true' else '',
                                                           '/dual' if dual == 'true' else '',
                                                           '/stem' if c16 == 'true' else '', dt.lower())
+    m = re.search(r'conv_pair_kernel<(\d+), (\d+), (\d+), (\d+), (\w+)>', name)
+    if m:   # the paired-fp16 head of DIR_FP16P (csrc/conv_pair.hip): <BM, BN, WGM, WGN, XP>
+        return 'conv_pair<%sx%s_%sw>' % (m.group(1), m.group(2), 'x' if m.group(5) == 'true' else '')
     m = re.search(r'conv_f32_kernel<(\d+)>', name)
     if m:   # the strict fp32 path (csrc/conv_f32.hip)
         return 'conv_f32<128x%s>' % m.group(1)
@@ -144,7 +147,7 @@ def pmc(fd, wd, out, traffic=None):
 
 
 # ---- per-kernel roofline table ---------------------------------------------------------------------
-ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'conv_f32<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
+ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'conv_f32<', 'conv_pair<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
 PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
 FOLLOW_UP = ('gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel')
 MEASURED_TF, MEASURED_GBS = 1582.0, 6305.0   # scripts/probes/*_ceiling.hip on a pool box (profiles/r02_*_ceiling.txt)
@@ -158,7 +161,8 @@ def bench_kernel_name(k):
             'gemm_nt_small_kernel': 'gemm_nt_f32', 'gemm_nt_f32_kernel': 'gemm_nt_f32',
             'maxpool_kernel': 'maxpool_3x3s2', 'upsample_add_kernel': 'upsample_add',
             'prep_input_f32_kernel': 'prep_input_f32', 'maxpool_f32_kernel': 'maxpool_f32',
-            'global_pool_f32_kernel': 'global_pool_f32', 'upsample_add_f32_kernel': 'upsample_add_f32'}.get(k, k)
+            'global_pool_f32_kernel': 'global_pool_f32', 'upsample_add_f32_kernel': 'upsample_add_f32',
+            'stem_pool_pair_kernel': 'stem_pool_pair', 'prep_input_pair_kernel': 'prep_input_pair'}.get(k, k)
 
 
 def layer_group(name):

@@ -175,7 +175,8 @@ def test_profile_tooling_knows_every_engine_kernel():
     assert len(names) > 100, names[:5]
     variants = set(ops.conv_variant_names())
     forward = {'stem_pool', 'prep_input', 'global_pool', 'gemm_nt_f32', 'maxpool_3x3s2', 'upsample_add',
-               'prep_input_f32', 'maxpool_f32', 'global_pool_f32', 'upsample_add_f32'}      # + the strict path's
+               'prep_input_f32', 'maxpool_f32', 'global_pool_f32', 'upsample_add_f32',      # + the strict path's
+               'stem_pool_pair', 'prep_input_pair'}                                        # + the paired head's
     other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_sort_kernel', 'rank_hist_kernel', 'rank_finalize_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
              'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'sim_split_lc_kernel', 'split_queries_kernel', 'fill_noise_kernel',
              'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel'}
@@ -184,6 +185,6 @@ def test_profile_tooling_knows_every_engine_kernel():
         if 'conv' in n and 'finalize' not in n and 'naive' not in n:
             m = re.match(r'^conv_igemm<([^>/]+)(/splitk|/dual)?>$', k)
             assert (m and m.group(1) in variants) or re.match(r'^conv_c3c1<(64|128)(,ds)?>$', k) or \
-                re.match(r'^conv_f32<128x(64|128)>$', k), (n, k)
+                re.match(r'^conv_f32<128x(64|128)>$', k) or re.match(r'^conv_pair<128x(64|128)_x?w>$', k), (n, k)
         else:
             assert k in forward or k in other, (n, k)
