@@ -170,6 +170,28 @@ int dir_conv_bn_act_pair(const void* x_hi, const void* x_lo, const void* w_hi, c
     DIR_CATCH
 }
 
+int dir_conv_pair_dual(const void* t2_hi, const void* t2_lo, const void* x_hi, const void* x_lo, const void* wcat_hi,
+                       const void* wcat_lo, const float* bias, void* y_hi, void* y_lo, int B, int H, int W, int Cin,
+                       int Cout, int relu, void* stream) {
+    DIR_TRY
+    if (!t2_hi || !t2_lo || !x_hi || !x_lo || !wcat_hi || !wcat_lo || !bias || !y_hi)
+        return fail(DIR_ERR_INVALID, "conv_pair_dual: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(DIR_ERR_INVALID, "conv_pair_dual: bad dimension");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const uint16_t*)t2_hi; a.x_lo = (const uint16_t*)t2_lo;
+    a.x2 = (const uint16_t*)x_hi; a.x2_lo = (const uint16_t*)x_lo;
+    a.w = (const uint16_t*)wcat_hi; a.w_lo = (const uint16_t*)wcat_lo;
+    a.bias = bias;
+    a.y = (uint16_t*)y_hi; a.y_lo = (uint16_t*)y_lo;
+    a.B = B; a.H = a.OH = H; a.W = a.OW = W; a.Cin = a.Cin2 = Cin; a.Cout = Cout;
+    a.R = a.S = 1; a.stride = 1; a.relu = relu ? 1 : 0;
+    a.M = B * H * W;
+    a.Ktot = 2 * Cin;
+    return conv_pair_launch(a, (hipStream_t)stream);
+    DIR_CATCH
+}
+
 int dir_prep_input_pair(const void* img, int img_format, const float* mean3, const float* std3, void* out_hi,
                         void* out_lo, int B, int H, int W, void* stream) {
     DIR_TRY

@@ -38,6 +38,7 @@ struct ConvArgs {
     // lo = fp16(v - hi) (~22 significant bits); x / w / res / y above are the hi planes, these the lo planes of the
     // same layout.  w_lo is required there; x_lo / res_lo / y_lo may be null (single-plane operand / output).
     const uint16_t* x_lo;
+    const uint16_t* x2_lo;   // ... and of the second K source (x2) in the two-source form
     const uint16_t* w_lo;
     const uint16_t* res_lo;
     uint16_t* y_lo;

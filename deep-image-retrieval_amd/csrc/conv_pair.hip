@@ -44,7 +44,11 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 // K-step = 32 input channels of one filter tap; a stage = Xh [BM][32] (+ Xl) + Wh [BN][32] + Wl [BN][32], rows of 64 B
 // whose four 16-byte chunks are swizzled by (row >> 2) & 3; two stages (48 KB at most): three workgroups share a CU, so
 // one's stores overlap another's loads - these layers are bound by HBM, not by the 3x MFMA count.
-template <int BM, int BN, int WGM, int WGN, bool XP>
+// DUAL (conv_igemm.hip's two-source idea, for the paired head's first block): the K dimension comes from TWO pixel-aligned
+// pair tensors of equal width - K-steps [0, Cin / 32) from x (t2: conv3's input), the rest from x2 (the block input: the
+// stride-1 downsample branch, resnet.py:134-141), weights concatenated along K, biases summed: relu([W3 | Wds] . [t2 ; x]
+// + b3 + bds) in one launch, and the 4P-wide downsample tensor (a pair: 2 x 1 GB at batch 32) is never written or read.
+template <int BM, int BN, int WGM, int WGN, bool XP, bool DUAL = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArgs a) {
     typedef FP16 DT;
     typedef DT::frag_t frag_t;
@@ -77,6 +81,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
         __builtin_amdgcn_make_buffer_rsrc((void*)(XP ? a.x_lo : a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2h = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2l =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL && XP ? a.x2_lo : a.x), 0, a.x_bytes, 0x00020000);
 
     // per-lane source offsets: chunk slot tid % 4 of LDS row tid / 4 (+ i * NT/4) holds source chunk slot ^ swz(row)
     const int srcchunk = (tid & 3) ^ ((tid >> 4) & 3);
@@ -118,14 +125,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
         wvoff[i] = (uint32_t)(((tile_n * BN + row) * a.Ktot + srcchunk * 8) * 2);
     }
 
-    auto issue = [&](int wstep, int tap, int koff, char* stage) {
+    auto issue = [&](int wstep, int tap, int koff, bool second, char* stage) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             char* dst = stage + (i * NT + wave * 64) * 16;
             const uint32_t v = ((xmask[i] >> tap) & 1u) ? (uint32_t)(xbase[i] + (one_tap ? 0 : koff)) : kOOBp;
             const int so = one_tap ? koff : 0;   // 1x1: the K-step rides in the scalar offset
-            dma16p(rsrc_xh, dst, v, so);
-            if (XP) dma16p(rsrc_xl, dst + XS, v, so);
+            if (DUAL && second) {                // same pixel, same width: only the tensor differs
+                dma16p(rsrc_x2h, dst, v, so);
+                if (XP) dma16p(rsrc_x2l, dst + XS, v, so);
+            } else {
+                dma16p(rsrc_xh, dst, v, so);
+                if (XP) dma16p(rsrc_xl, dst + XS, v, so);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -183,7 +195,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
     const int cpb = a.Cin / BK;
     const int T = a.T;
     int tap = 0, cc = 0, r = 0, s = 0;
-    auto koff_now = [&]() { return ((r * a.W + s) * a.Cin + cc * BK) * 2; };
+    // (DUAL: flat 1x1 only - tap == 0, cc counts K-steps over both sources, the second one starts at cc == cpb)
+    auto second_now = [&]() { return DUAL && cc >= cpb; };
+    auto koff_now = [&]() { return ((r * a.W + s) * a.Cin + (second_now() ? cc - cpb : cc) * BK) * 2; };
     auto wstep_now = [&]() { return tap * cpb + cc; };
     auto advance = [&]() {
         ++tap;
@@ -196,13 +210,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
             }
         }
     };
-    issue(wstep_now(), tap, koff_now(), smem);
+    issue(wstep_now(), tap, koff_now(), second_now(), smem);
     advance();
     for (int t = 0; t < T; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ring_barrier();   // stage t landed everywhere; everyone is done reading the other slot
         if (t + 1 < T) {
-            issue(wstep_now(), tap, koff_now(), smem + ((t + 1) & 1) * STAGE_BYTES);
+            issue(wstep_now(), tap, koff_now(), second_now(), smem + ((t + 1) & 1) * STAGE_BYTES);
             advance();
         }
         compute(smem + (t & 1) * STAGE_BYTES);
@@ -294,7 +308,7 @@ static void fastdiv_init_p(uint32_t d, uint32_t& mul, uint32_t& shr) {
     shr = l - 1;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool XP>
+template <int BM, int BN, int WGM, int WGN, bool XP, bool DUAL = false>
 static hipError_t launch_pair(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TN = BN / WGN / 32;
@@ -303,7 +317,7 @@ static hipError_t launch_pair(const ConvArgs& a, hipStream_t stream) {
     constexpr int EPI_BYTES = (NT / 64) * 32 * EROW;
     constexpr int LDS = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS <= 64 * 1024, "two or three workgroups per CU");
-    auto kern = conv_pair_kernel<BM, BN, WGM, WGN, XP>;
+    auto kern = conv_pair_kernel<BM, BN, WGM, WGN, XP, DUAL>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -325,6 +339,7 @@ static hipError_t launch_pair(const ConvArgs& a, hipStream_t stream) {
 static bool pair_wide(const ConvArgs& a) { return a.Cout % 128 == 0; }
 
 const char* conv_pair_variant_name(const ConvArgs& a) {
+    if (a.x2) return "128x128_xw/dual";
     return pair_wide(a) ? (a.x_lo ? "128x128_xw" : "128x128_w") : (a.x_lo ? "128x64_xw" : "128x64_w");
 }
 
@@ -341,7 +356,14 @@ int conv_pair_launch(const ConvArgs& a, hipStream_t stream) {
     for (const void* p : ptrs)
         if ((uintptr_t)p & 15) return fail(DIR_ERR_INVALID, "conv_pair: tensors must be 16-byte aligned");
     hipError_t e;
-    if (pair_wide(a))
+    if (a.x2) {   // two-source form: conv3 + the stride-1 downsample of the paired head's first block
+        const bool flat = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW;
+        if (!flat || a.Cin2 != a.Cin || a.Ktot != 2 * a.Cin || !a.x_lo || !a.x2_lo || a.res || a.Cout % 128 != 0 ||
+            ((uintptr_t)a.x2 & 15) || ((uintptr_t)a.x2_lo & 15))
+            return fail(DIR_ERR_INVALID, "conv_pair: the two-source form takes two pixel-aligned pair tensors of equal width, "
+                                         "1x1 stride 1, Cout % 128 == 0, no residual");
+        e = launch_pair<128, 128, 2, 2, true, true>(a, stream);
+    } else if (pair_wide(a))
         e = a.x_lo ? launch_pair<128, 128, 2, 2, true>(a, stream) : launch_pair<128, 128, 2, 2, false>(a, stream);
     else
         e = a.x_lo ? launch_pair<128, 64, 2, 2, true>(a, stream) : launch_pair<128, 64, 2, 2, false>(a, stream);
@@ -528,6 +550,195 @@ __global__ void __launch_bounds__(256) stem_pool_pair_kernel(const StemPairArgs 
     ovf.flush(a.ovf);
 }
 
+// ---- persistent form --------------------------------------------------------------------------------------------------
+// The one-tile-per-workgroup kernel above re-loads 64 KB of filter per 3 x 15 pooled tile and runs load / MFMA / pool
+// strictly one after the other (1.42 ms at batch 32).  Here one 8-wave workgroup per CU walks a strided list of tiles with
+// the FILTER PAIR IN REGISTERS: wave w owns channel tile w & 1 and conv rows 2 (w >> 1), 2 (w >> 1) + 1 and holds that
+// channel tile's 16 hi + 16 lo fragments (128 VGPRs, fetched once, straight in MFMA operand layout).  Two patch-pair
+// buffers (the next tile's patch is in flight while this one is multiplied and pooled) + the fp32 conv tile: 128 KiB.
+__global__ void __launch_bounds__(512) stem_pool_pair_persist_kernel(const StemPairArgs a) {
+    typedef FP16 DT;
+    typedef DT::frag_t frag_t;
+    constexpr int PTH = 3, PTW = 15;
+    constexpr int TH = 8, TW = 32;
+    constexpr int QW = TW + 3;
+    constexpr int QP = (TH + 3) * QW;
+    constexpr int PLANE = 512 * 16;
+    constexpr int PATCH = 2 * PLANE;            // one plane pair of channel halves: 16 KiB (hi or lo)
+    constexpr int PBUF = 2 * PATCH;             // hi + lo
+    constexpr int TILE_OFF = 2 * PBUF;          // conv tile behind the two patch buffers
+    constexpr int BIAS_OFF = TILE_OFF + TH * TW * 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int ci = wave & 1, rp = wave >> 1;
+
+    const int tiles_x = (a.PW + PTW - 1) / PTW;
+    const int tiles_y = (a.PH + PTH - 1) / PTH;
+    const int ntiles = a.B * tiles_y * tiles_x;
+
+    const __amdgpu_buffer_rsrc_t rsrc_xh = __builtin_amdgcn_make_buffer_rsrc((void*)a.xh, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_xl = __builtin_amdgcn_make_buffer_rsrc((void*)a.xl, 0, a.x_bytes, 0x00020000);
+
+    frag_t wfh[4][4], wfl[4][4];
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const size_t o = (size_t)(ci * 32 + lrow) * 256 + R * 64 + ks * 16 + lhi * 8;
+            wfh[R][ks] = __builtin_bit_cast(frag_t, gload16(a.wh + o));
+            wfl[R][ks] = __builtin_bit_cast(frag_t, gload16(a.wl + o));
+        }
+    float* lbias = (float*)(smem + BIAS_OFF);
+    if (tid < 64) lbias[tid] = a.bias[tid];
+
+    auto issue_patch = [&](int tile, char* dst) {
+        int wg = tile;
+        const int tx = wg % tiles_x;
+        wg /= tiles_x;
+        const int ty = wg % tiles_y;
+        const int b = wg / tiles_y;
+        const int oy0 = 2 * ty * PTH - 1, ox0 = 2 * tx * PTW - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int P = i * 512 + tid;
+            const int plane = P >> 9, p = P & 511;
+            const int py = p / QW, px = p - py * QW;
+            const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
+            const bool ok = p < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
+            const uint32_t v = ok ? (uint32_t)((((b * a.H2 + iy) * a.W2 + ix) * 16 + plane * 8) * 2) : kOOBp;
+            dma16p(rsrc_xh, dst + (i * 512 + wave * 64) * 16, v, 0);
+            dma16p(rsrc_xl, dst + PATCH + (i * 512 + wave * 64) * 16, v, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    Ovf<DT> ovf;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // filter in registers, bias in LDS, before the counted waits
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {   // pin: the waits for these loads must not be re-executed inside the loop
+            asm volatile("" : "+v"(wfh[R][ks]));
+            asm volatile("" : "+v"(wfl[R][ks]));
+        }
+    issue_patch(tile, smem);
+    int cur = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const char* pbuf = smem + cur * PBUF;
+        // the other buffer was last read by the MFMA phase of the previous tile, which every wave left before the barrier
+        // in front of that tile's pooling
+        if (next < ntiles) {
+            issue_patch(next, smem + (cur ^ 1) * PBUF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this tile's patch; the 4 newest ops may fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ring_barrier();   // patch landed everywhere; everyone is done pooling the previous tile
+
+        f32x16_t acc[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t b4 = *(const f32x4_t*)(lbias + ci * 32 + 8 * g + 4 * lhi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = b4[e];
+        }
+#pragma unroll
+        for (int R = 0; R < 4; ++R)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                frag_t xh[2], xl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int p = (rp * 2 + j + R) * QW + lrow + ks;
+                    xh[j] = *(const frag_t*)(pbuf + lhi * PLANE + p * 16);
+                    xl[j] = *(const frag_t*)(pbuf + PATCH + lhi * PLANE + p * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[j] = DT::mfma32(wfh[R][ks], xh[j], acc[j]);
+                    acc[j] = DT::mfma32(wfh[R][ks], xl[j], acc[j]);
+                    acc[j] = DT::mfma32(wfl[R][ks], xh[j], acc[j]);
+                }
+            }
+
+        int wg = tile;
+        const int tx = wg % tiles_x;
+        wg /= tiles_x;
+        const int ty = wg % tiles_y;
+        const int b = wg / tiles_y;
+        const int ph0 = ty * PTH, pw0 = tx * PTW;
+        const int oy0 = 2 * ph0 - 1, ox0 = 2 * pw0 - 1;
+        char* ctile = smem + TILE_OFF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tyy = rp * 2 + j;
+            const int oy = oy0 + tyy, ox = ox0 + lrow;
+            const int inmask = ((unsigned)oy < (unsigned)a.OH && (unsigned)ox < (unsigned)a.OW) ? -1 : 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[j][4 * g + e];
+                    v[e] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, t), 0) & inmask);
+                }
+                const int c16 = 8 * ci + 2 * g + lhi;
+                *(f32x4_t*)(ctile + (tyy * TW + lrow) * 256 + ((c16 ^ (lrow & 7)) << 4)) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ring_barrier();   // conv tile complete; every wave is past its patch reads
+
+        for (int it = tid; it < PTH * PTW * 8; it += 512) {
+            const int c8 = it & 7;
+            const int pp = it >> 3;
+            const int py = pp / PTW, px = pp - py * PTW;
+            const int ph = ph0 + py, pw = pw0 + px;
+            if (ph >= a.PH || pw >= a.PW) continue;
+            f32x4_t m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int yy = 2 * py + dy, xx = 2 * px + dx;
+                    const char* row = ctile + (yy * TW + xx) * 256;
+                    const f32x4_t u0 = *(const f32x4_t*)(row + (((2 * c8) ^ (xx & 7)) << 4));
+                    const f32x4_t u1 = *(const f32x4_t*)(row + (((2 * c8 + 1) ^ (xx & 7)) << 4));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m0[e] = fmaxf(m0[e], u0[e]);
+                        m1[e] = fmaxf(m1[e], u1[e]);
+                    }
+                }
+            u32x4_t oh, ol;
+            const float mv[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t hh, ll;
+                split2(mv[2 * e], mv[2 * e + 1], hh, ll);
+                oh[e] = hh;
+                ol[e] = ll;
+            }
+            const size_t o = ((size_t)(b * a.PH + ph) * a.PW + pw) * 64 + c8 * 8;
+            gstore16(a.yh + o, oh);
+            gstore16(a.yl + o, ol);
+            ovf.see(oh);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pooling reads retired before the next tile's barrier
+        cur ^= 1;
+    }
+    ovf.flush(a.ovf);
+}
+
 int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
                           void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream, int* ovf) {
     if (!s2d_hi || !s2d_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo)
@@ -547,10 +758,20 @@ int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_
     a.PW = (OW - 1) / 2 + 1;
     a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
     a.ovf = ovf;
+    const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
+    const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting (read per launch: the tests flip it)
+    if (!v1) {
+        constexpr int LDSP = 2 * 2 * 2 * 512 * 16 + 8 * 32 * 256 + 256;   // two patch pairs + the fp32 conv tile + bias
+        static std::atomic<uint64_t> attr_p{0};
+        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_pair_persist_kernel, LDSP, attr_p));
+        const long grid = blocks < cu_count() ? blocks : cu_count();
+        hipLaunchKernelGGL(stem_pool_pair_persist_kernel, dim3((unsigned)grid), dim3(512), LDSP, stream, a);
+        DIR_HIP_CHECK(hipGetLastError());
+        return DIR_OK;
+    }
     constexpr int LDS = 2 * 2 * 512 * 16 + 2 * 4 * 8192;   // patch pair + filter pair = 96 KiB
     static std::atomic<uint64_t> attr_done{0};
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_pair_kernel, LDS, attr_done));
-    const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
     hipLaunchKernelGGL(stem_pool_pair_kernel, dim3((unsigned)blocks), dim3(256), LDS, stream, a);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;

@@ -29,8 +29,10 @@ struct ConvLayer {
     // conv3 of a stage's first block whose downsample qualifies (conv_c3c1.hip, DS form): this conv's
     // weights with the downsample's appended along K, and the sum of the two folded-BN biases
     uint16_t* d_w_ds = nullptr;
+    uint16_t* d_w_ds_lo = nullptr;   // ... its lo plane (DIR_FP16P paired head, conv_pair.hip's two-source form)
     float* d_bias_ds = nullptr;
     std::vector<uint16_t> h_w;   // host copies, alive during finalize() only
+    std::vector<uint16_t> h_w_lo;
     std::vector<float> h_bias;
     std::map<long, int> tuned;  // M -> variant index chosen by autotune
 };
@@ -48,7 +50,7 @@ struct ProfSlot {
 
 struct Plan {  // byte offsets into the caller's workspace for one (B, H, W)
     size_t s2d, stem, bufA, bufB, t1, t2, ds, x4, splitk, pooled, fcout, total;
-    size_t lo_s2d, lo_bufA, lo_bufB, lo_t1, lo_t2, lo_ds;   // DIR_FP16P: lo planes of the paired head's tensors
+    size_t lo_s2d, lo_stem, lo_t1, lo_t2, lo_ds;   // DIR_FP16P: lo planes of the paired head's tensors
     int H2, W2, OH1, OW1, PH, PW;
 };
 
@@ -98,9 +100,10 @@ struct dir_engine {
     int run_conv(dir::ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
                  int H, int W, int OH, int OW, hipStream_t stream, bool rev_m = false);
     // DIR_FP16P head (conv_pair.hip): one convolution on fp16 pairs; x_lo / res_lo / y_lo may be null
+    // x2 / x2_lo set: the two-source form (conv3 + the block's stride-1 downsample as one GEMM over [t2 ; block input])
     int run_conv_pair(dir::ConvLayer& L, const uint16_t* x, const uint16_t* x_lo, const uint16_t* res,
                       const uint16_t* res_lo, uint16_t* y, uint16_t* y_lo, int B, int H, int W, int OH, int OW,
-                      hipStream_t stream);
+                      hipStream_t stream, const uint16_t* x2 = nullptr, const uint16_t* x2_lo = nullptr);
     // image -> stem -> the first pair_blocks residual blocks, everything a pair of fp16 planes; leaves the last block's
     // output (hi plane only: what layer2 reads) in *cur and reports the map size and the next block index
     int forward_pair_head(const void* img, int B, int H, int W, int fmt, char* base, const dir::Plan& p,

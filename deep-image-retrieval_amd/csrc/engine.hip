@@ -234,6 +234,7 @@ int dir_engine::finalize(int dt) {
             for (size_t i = 0; i < packed.size(); ++i) lo16[i] = f32_to_f16_bits(packed[i] - f16_bits_to_f32(packed16[i]));
             DIR_HIP_CHECK(hipMalloc((void**)&L.d_w_lo, lo16.size() * 2));
             DIR_HIP_CHECK(hipMemcpy(L.d_w_lo, lo16.data(), lo16.size() * 2, hipMemcpyHostToDevice));
+            L.h_w_lo.swap(lo16);
         }
         L.h_w.swap(packed16);
         L.h_bias.swap(bias);
@@ -244,10 +245,12 @@ int dir_engine::finalize(int dt) {
     // materialised: conv_c3c1's DS form (layer1: 64 + 64 channels, stride 1) or the two-source form of the
     // implicit-GEMM kernel (layers 2-4, stride 2).
     for (const BlockDef& bd : blocks) {
-        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0 || dt == DIR_F32 || is_pair[bd.conv3]) continue;
+        if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0 || dt == DIR_F32) continue;
         ConvLayer& c3 = convs[bd.conv3];
         const ConvLayer& ds = convs[bd.down];
         if (ds.R != 1 || ds.S != 1 || ds.pad != 0 || ds.Cout != c3.Cout || ds.Cin % 64 != 0 || c3.Cin % 64 != 0) continue;
+        // paired head: conv_pair.hip's two-source form takes pixel-aligned sources of equal width only (layer1's first block)
+        if (is_pair[bd.conv3] && (ds.stride != 1 || ds.Cin != c3.Cin || c3.Cout % 128 != 0)) continue;
         const int K3 = c3.Cin, Kd = ds.Cin, N = c3.Cout;
         std::vector<uint16_t> cat((size_t)N * (K3 + Kd));
         std::vector<float> bsum(N);
@@ -260,8 +263,17 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMemcpy(c3.d_w_ds, cat.data(), cat.size() * 2, hipMemcpyHostToDevice));
         DIR_HIP_CHECK(hipMalloc((void**)&c3.d_bias_ds, N * 4));
         DIR_HIP_CHECK(hipMemcpy(c3.d_bias_ds, bsum.data(), N * 4, hipMemcpyHostToDevice));
+        if (is_pair[bd.conv3]) {   // the lo planes, concatenated the same way
+            for (int o = 0; o < N; ++o) {
+                memcpy(&cat[(size_t)o * (K3 + Kd)], &c3.h_w_lo[(size_t)o * K3], K3 * 2);
+                memcpy(&cat[(size_t)o * (K3 + Kd) + K3], &ds.h_w_lo[(size_t)o * Kd], Kd * 2);
+            }
+            DIR_HIP_CHECK(hipMalloc((void**)&c3.d_w_ds_lo, cat.size() * 2));
+            DIR_HIP_CHECK(hipMemcpy(c3.d_w_ds_lo, cat.data(), cat.size() * 2, hipMemcpyHostToDevice));
+        }
     }
     for (ConvLayer& L : convs) {
+        std::vector<uint16_t>().swap(L.h_w_lo);
         std::vector<uint16_t>().swap(L.h_w);
         std::vector<float>().swap(L.h_bias);
     }
@@ -305,6 +317,8 @@ void dir_engine::release() {
         L.d_w_lo = nullptr;
         if (L.d_bias) (void)hipFree(L.d_bias);
         if (L.d_w_ds) (void)hipFree(L.d_w_ds);
+        if (L.d_w_ds_lo) (void)hipFree(L.d_w_ds_lo);
+        L.d_w_ds_lo = nullptr;
         if (L.d_bias_ds) (void)hipFree(L.d_bias_ds);
         L.d_w = L.d_w_ds = nullptr;
         L.d_bias = L.d_bias_ds = nullptr;
@@ -380,15 +394,14 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->t2 = take(t2 ? t2 : 256);
     p->ds = take(ds ? ds : 256);
     p->x4 = take(x4 ? x4 : 256);
-    p->lo_s2d = p->lo_bufA = p->lo_bufB = p->lo_t1 = p->lo_t2 = p->lo_ds = 0;
-    if (dtype == DIR_FP16P) {   // lo planes of the paired head: image, block outputs, t1 / t2 / downsample of its blocks
-        size_t pio = (size_t)B * p->PH * p->PW * 64 * 2, pt1 = 0, pt2 = 0, pds = 0;
+    p->lo_s2d = p->lo_stem = p->lo_t1 = p->lo_t2 = p->lo_ds = 0;
+    if (dtype == DIR_FP16P) {   // lo planes of the paired head: image, stem output, t1 / t2 / downsample of its blocks
+        size_t pt1 = 0, pt2 = 0, pds = 0;
         int ph = p->PH, pw = p->PW;
         for (int bi = 0; bi < pair_blocks && bi < (int)blocks.size(); ++bi) {
             const BlockDef& bd = blocks[bi];
             const int oh = conv_out(ph, 3, bd.stride, 1), ow = conv_out(pw, 3, bd.stride, 1);
             const ConvLayer& c1 = convs[bd.conv1];
-            const ConvLayer& cl = convs[desc.bottleneck ? bd.conv3 : bd.conv2];
             if (desc.bottleneck) {
                 pt1 = std::max(pt1, (size_t)B * ph * pw * c1.Cout * 2);
                 pt2 = std::max(pt2, (size_t)B * oh * ow * convs[bd.conv2].Cout * 2);
@@ -396,13 +409,11 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
                 pt1 = std::max(pt1, (size_t)B * oh * ow * c1.Cout * 2);
             }
             if (bd.down >= 0) pds = std::max(pds, (size_t)B * oh * ow * convs[bd.down].Cout * 2);
-            pio = std::max(pio, (size_t)B * oh * ow * cl.Cout * 2);
             ph = oh;
             pw = ow;
         }
         p->lo_s2d = take((size_t)B * p->H2 * p->W2 * 16 * 2);
-        p->lo_bufA = take(pio);
-        p->lo_bufB = take(pio);
+        p->lo_stem = take((size_t)B * p->PH * p->PW * 64 * 2);
         p->lo_t1 = take(pt1 ? pt1 : 256);
         p->lo_t2 = take(pt2 ? pt2 : 256);
         p->lo_ds = take(pds ? pds : 256);
@@ -536,8 +547,9 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
 // ---- one convolution on fp16 pairs (DIR_FP16P head, conv_pair.hip) -------------------------------------------------
 int dir_engine::run_conv_pair(ConvLayer& L, const uint16_t* x, const uint16_t* x_lo, const uint16_t* res,
                               const uint16_t* res_lo, uint16_t* y, uint16_t* y_lo, int B, int H, int W, int OH, int OW,
-                              hipStream_t stream) {
+                              hipStream_t stream, const uint16_t* x2, const uint16_t* x2_lo) {
     if (!L.d_w_lo) return fail(DIR_ERR_STATE, "paired conv on a layer without a lo weight plane: " + L.name);
+    if (x2 && !L.d_w_ds_lo) return fail(DIR_ERR_STATE, "two-source paired conv without concatenated weights: " + L.name);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
@@ -564,13 +576,23 @@ int dir_engine::run_conv_pair(ConvLayer& L, const uint16_t* x, const uint16_t* x
     a.ovf = d_ovf;
     a.M = B * OH * OW;
     a.Ktot = a.R * a.S * a.Cin;
+    if (x2) {   // conv3 + the block's stride-1 downsample: K = [t2 ; block input], weights / biases concatenated at finalize
+        a.x2 = x2;
+        a.x2_lo = x2_lo;
+        a.Cin2 = a.Cin;
+        a.w = L.d_w_ds;
+        a.w_lo = L.d_w_ds_lo;
+        a.bias = L.d_bias_ds;
+        a.Ktot = 2 * a.Cin;
+    }
     const double macs = (double)a.M * L.Cout * (double)a.Ktot;
     // every tensor a pair: twice the bytes of the 16-bit form (single-plane operands counted once)
-    const double bytes = 2.0 * ((double)B * H * W * a.Cin * (x_lo ? 2 : 1) + (double)a.M * L.Cout * (y_lo ? 2 : 1) +
+    const double bytes = 2.0 * ((double)B * H * W * a.Cin * (x_lo ? 2 : 1) * (x2 ? 2 : 1) + (double)a.M * L.Cout * (y_lo ? 2 : 1) +
                                 (double)a.M * L.Cout * (res ? (res_lo ? 2 : 1) : 0) + 2.0 * L.Cout * a.Ktot);
     int rc = DIR_OK;
     if (profiling && !prof_paused)
-        rc = prof_begin(L.name, std::string("conv_pair<") + conv_pair_variant_name(a) + ">", 2.0 * macs, bytes, stream);
+        rc = prof_begin(x2 ? L.name.substr(0, L.name.rfind('.')) + ".ds+conv3" : L.name,
+                        std::string("conv_pair<") + conv_pair_variant_name(a) + ">", 2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     rc = conv_pair_launch(a, stream);
     if (rc != DIR_OK) return rc;
@@ -585,7 +607,7 @@ int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt,
     uint16_t* s2d = (uint16_t*)(base + p.s2d);
     uint16_t* s2d_lo = (uint16_t*)(base + p.lo_s2d);
     uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
-    uint16_t* const pl[2] = {(uint16_t*)(base + p.lo_bufA), (uint16_t*)(base + p.lo_bufB)};
+    uint16_t* stem_lo = (uint16_t*)(base + p.lo_stem);
     uint16_t* t1 = (uint16_t*)(base + p.t1);
     uint16_t* t2 = (uint16_t*)(base + p.t2);
     uint16_t* ds = (uint16_t*)(base + p.ds);
@@ -610,37 +632,47 @@ int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt,
     rc = prof_begin("conv1+maxpool", "stem_pool_pair", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
                     4.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256), stream);
     if (rc != DIR_OK) return rc;
-    rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, pp[cur], pl[cur], B, p.H2, p.W2,
+    rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, pp[cur], stem_lo, B, p.H2, p.W2,
                                p.OH1, p.OW1, stream, d_ovf);
     if (rc != DIR_OK) return rc;
     if ((rc = prof_end(stream)) != DIR_OK) return rc;
 
+    // Which tensors are pairs (tests/precision_decomposition.py prices every storage point): the image, the stem output
+    // and everything INSIDE a block (t1, t2, the downsample branch) - the block outputs, 4P wide and read three times
+    // each, are single fp16 planes: their rounding costs 7e-6 of the 1e-4 budget and a third of the head's bytes.
     int h = p.PH, w = p.PW;
     const size_t nb = std::min((size_t)pair_blocks, blocks.size());
     for (size_t bi = 0; bi < nb; ++bi) {
         BlockDef& bd = blocks[bi];
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
         const int nxt = cur ^ 1;
-        // the block after the paired region reads single fp16 planes: the last paired block writes its hi plane only
-        uint16_t* out_lo = bi + 1 < nb ? pl[nxt] : nullptr;
-        const uint16_t *resid = pp[cur], *resid_lo = pl[cur];
-        if (bd.down >= 0) {
-            rc = run_conv_pair(convs[bd.down], pp[cur], pl[cur], nullptr, nullptr, ds, ds_lo, B, h, w, oh, ow, stream);
+        const uint16_t* x = pp[cur];
+        const uint16_t* x_lo = bi == 0 ? stem_lo : nullptr;
+        const uint16_t *resid = x, *resid_lo = x_lo;
+        // first block of a stage: the downsample rides in conv3's GEMM when it is pixel-aligned with t2 (stride 1, same
+        // width: layer1); otherwise it is its own paired conv
+        const bool fuse_ds = bd.down >= 0 && desc.bottleneck && convs[bd.conv3].d_w_ds_lo != nullptr && x_lo != nullptr;
+        if (bd.down >= 0 && !fuse_ds) {
+            rc = run_conv_pair(convs[bd.down], x, x_lo, nullptr, nullptr, ds, ds_lo, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
             resid = ds;
             resid_lo = ds_lo;
         }
         if (desc.bottleneck) {
-            rc = run_conv_pair(convs[bd.conv1], pp[cur], pl[cur], nullptr, nullptr, t1, t1_lo, B, h, w, h, w, stream);
+            rc = run_conv_pair(convs[bd.conv1], x, x_lo, nullptr, nullptr, t1, t1_lo, B, h, w, h, w, stream);
             if (rc != DIR_OK) return rc;
             rc = run_conv_pair(convs[bd.conv2], t1, t1_lo, nullptr, nullptr, t2, t2_lo, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
-            rc = run_conv_pair(convs[bd.conv3], t2, t2_lo, resid, resid_lo, pp[nxt], out_lo, B, oh, ow, oh, ow, stream);
+            if (fuse_ds)
+                rc = run_conv_pair(convs[bd.conv3], t2, t2_lo, nullptr, nullptr, pp[nxt], nullptr, B, oh, ow, oh, ow, stream,
+                                   x, x_lo);
+            else
+                rc = run_conv_pair(convs[bd.conv3], t2, t2_lo, resid, resid_lo, pp[nxt], nullptr, B, oh, ow, oh, ow, stream);
             if (rc != DIR_OK) return rc;
         } else {
-            rc = run_conv_pair(convs[bd.conv1], pp[cur], pl[cur], nullptr, nullptr, t1, t1_lo, B, h, w, oh, ow, stream);
+            rc = run_conv_pair(convs[bd.conv1], x, x_lo, nullptr, nullptr, t1, t1_lo, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
-            rc = run_conv_pair(convs[bd.conv2], t1, t1_lo, resid, resid_lo, pp[nxt], out_lo, B, oh, ow, oh, ow, stream);
+            rc = run_conv_pair(convs[bd.conv2], t1, t1_lo, resid, resid_lo, pp[nxt], nullptr, B, oh, ow, oh, ow, stream);
             if (rc != DIR_OK) return rc;
         }
         cur = nxt;

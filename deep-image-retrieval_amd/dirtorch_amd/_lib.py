@@ -68,6 +68,7 @@ SIGNATURES = {
                         + [c_void_p]),
     'dir_conv_bn_act_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
     'dir_conv_bn_act_pair': (c_int, [c_void_p] * 4 + [c_void_p] + [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
+    'dir_conv_pair_dual': (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_void_p]),
     'dir_prep_input_pair': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_void_p]),
     'dir_stem_pool_pair': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),

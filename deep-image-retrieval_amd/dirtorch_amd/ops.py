@@ -362,6 +362,22 @@ def conv_bn_act_pair(x, w, bias, res=None, stride=1, pad=0, relu=True, pair_out=
     return y_hi, y_lo
 
 
+def conv_pair_dual(t2, x, wcat, bias, relu=True, pair_out=True):
+    """dir_conv_pair_dual: y = act([w3 | wds] . [t2 ; x] + bias); t2, x = (hi, lo) [B,H,W,Cin], wcat = (hi, lo)
+    [Cout, 2 Cin] (or [Cout,1,1,2 Cin]).  Returns (y_hi, y_lo)."""
+    (t_hi, t_lo), (x_hi, x_lo), (w_hi, w_lo) = t2, x, wcat
+    _need_cuda(t_hi, t_lo, x_hi, x_lo, w_hi, w_lo, bias)
+    B, H, W, Cin = t_hi.shape
+    Cout = w_hi.shape[0]
+    if w_hi.numel() != Cout * 2 * Cin or x_hi.shape != t_hi.shape:
+        raise ValueError('shape mismatch')
+    y_hi = torch.empty(B, H, W, Cout, dtype=torch.float16, device=t_hi.device)
+    y_lo = torch.empty_like(y_hi) if pair_out else None
+    call('dir_conv_pair_dual', ptr(t_hi), ptr(t_lo), ptr(x_hi), ptr(x_lo), ptr(w_hi), ptr(w_lo), ptr(bias), ptr(y_hi),
+         ptr(y_lo), B, H, W, Cin, Cout, int(bool(relu)), stream_ptr())
+    return y_hi, y_lo
+
+
 def prep_input_pair(img, mean=None, std=None):
     """fp32 NCHW (normalised) or uint8 NHWC image batch -> space-to-depth NHWC16 stem input as an fp16 pair."""
     _need_cuda(img)

@@ -135,6 +135,10 @@ int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const
  *   dir_conv_bn_act_pair  Conv2d + eval BatchNorm (+ residual add) (+ ReLU), dirtorch/nets/backbones/resnet.py:56-63,
  *                         70-85: x [B,H,W,Cin], w [Cout][R][S][Cin], res / y [B,OH,OW,Cout]; Cin % 32 == 0,
  *                         Cout % 64 == 0, R, S <= 4; x_lo / res_lo / y_lo may be NULL (single-plane operand / output)
+ *   dir_conv_pair_dual    conv3 + bn3 + the block's STRIDE-1 downsample branch + add + ReLU of layer1's first bottleneck
+ *                         as one GEMM over two pixel-aligned pair tensors of equal width (resnet.py:78-85 with :134-141):
+ *                         y = act([w3 | wds] . [t2 ; x] + bias3 + bias_ds); t2, x [B,H,W,Cin], wcat [Cout][2 Cin],
+ *                         Cout % 128 == 0; the 4P-wide downsample tensor is neither written nor read
  *   dir_prep_input_pair   ToTensor + Normalize (dirtorch/utils/transforms.py:617-623) -> space-to-depth pair
  *                         [B, ceil(H/2), ceil(W/2), 16] x 2
  *   dir_stem_pool_pair    conv 7x7 s2 + BN + ReLU + MaxPool 3x3 s2 (resnet.py:115-119) from that pair and the 4x4x16
@@ -142,6 +146,9 @@ int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const
 int dir_conv_bn_act_pair(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                          const void* res_hi, const void* res_lo, void* y_hi, void* y_lo, int B, int H, int W, int Cin,
                          int Cout, int R, int S, int stride, int pad, int OH, int OW, int relu, void* stream);
+int dir_conv_pair_dual(const void* t2_hi, const void* t2_lo, const void* x_hi, const void* x_lo, const void* wcat_hi,
+                       const void* wcat_lo, const float* bias, void* y_hi, void* y_lo, int B, int H, int W, int Cin,
+                       int Cout, int relu, void* stream);
 int dir_prep_input_pair(const void* img, int img_format, const float* mean3, const float* std3, void* out_hi,
                         void* out_lo, int B, int H, int W, void* stream);
 int dir_stem_pool_pair(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,

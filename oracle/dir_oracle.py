@@ -82,8 +82,9 @@ def resnet_features(sd, arch, x, quant=None, with_x4=False):
     """ResNet.forward up to layer4 (fc_out == 0 for *_rmac): [B,3,H,W] -> [B,C,h,w] fp32.
     with_x4 = the out_layer == -1 form (resnet.py:166-167): returns (layer3 map, layer4 map)."""
     bottleneck, layers = ARCH[arch]
-    # quant = 'fp16p' (DIR_FP16P): image, stem and the first `pair_stages` stages keep fp16 PAIRS (~22 bits), the last
-    # paired block hands a single fp16 plane to the rest of the trunk, which is 'fp16'
+    # quant = 'fp16p' (DIR_FP16P): the image, the stem and - inside the first `pair_stages` stages - the weights and the
+    # tensors between a bottleneck's convs (t1, t2, the downsample branch) are fp16 PAIRS (~22 bits); every block OUTPUT
+    # (the 4P-wide residual carry) is a single fp16 plane, and the rest of the trunk is 'fp16'
     fp16p = quant == 'fp16p' or (isinstance(quant, tuple) and quant[0] == 'fp16p')
     pair_stages = (quant[1] if isinstance(quant, tuple) else 1) if fp16p else 0
     tail_quant = 'fp16' if fp16p else quant
@@ -110,8 +111,7 @@ def resnet_features(sd, arch, x, quant=None, with_x4=False):
             if j == 0 and (stride != 1 or inplanes != planes * exp):
                 residual = _q(_conv_bn(sd, x, pre + '.downsample.0.weight', pre + '.downsample.1',
                                        stride, 0, quant), quant)
-            last_pair = fp16p and s == pair_stages - 1 and j == layers[s] - 1   # what the fp16 tail reads
-            x = _q(F.relu(out + residual), tail_quant if last_pair else quant)
+            x = _q(F.relu(out + residual), tail_quant)     # block outputs: one plane in every mode
             inplanes = planes * exp
         if s == 2:
             x4 = x

@@ -55,9 +55,10 @@ def short(name):
                                                           '/splitk' if sk == 'true' else '',
                                                           '/dual' if dual == 'true' else '',
                                                           '/stem' if c16 == 'true' else '', dt.lower())
-    m = re.search(r'conv_pair_kernel<(\d+), (\d+), (\d+), (\d+), (\w+)>', name)
-    if m:   # the paired-fp16 head of DIR_FP16P (csrc/conv_pair.hip): <BM, BN, WGM, WGN, XP>
-        return 'conv_pair<%sx%s_%sw>' % (m.group(1), m.group(2), 'x' if m.group(5) == 'true' else '')
+    m = re.search(r'conv_pair_kernel<(\d+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>', name)
+    if m:   # the paired-fp16 head of DIR_FP16P (csrc/conv_pair.hip): <BM, BN, WGM, WGN, XP[, DUAL]>
+        return 'conv_pair<%sx%s_%sw%s>' % (m.group(1), m.group(2), 'x' if m.group(5) == 'true' else '',
+                                           '/dual' if m.group(6) == 'true' else '')
     m = re.search(r'conv_f32_kernel<(\d+)>', name)
     if m:   # the strict fp32 path (csrc/conv_f32.hip)
         return 'conv_f32<128x%s>' % m.group(1)
@@ -162,7 +163,8 @@ def bench_kernel_name(k):
             'maxpool_kernel': 'maxpool_3x3s2', 'upsample_add_kernel': 'upsample_add',
             'prep_input_f32_kernel': 'prep_input_f32', 'maxpool_f32_kernel': 'maxpool_f32',
             'global_pool_f32_kernel': 'global_pool_f32', 'upsample_add_f32_kernel': 'upsample_add_f32',
-            'stem_pool_pair_kernel': 'stem_pool_pair', 'prep_input_pair_kernel': 'prep_input_pair'}.get(k, k)
+            'stem_pool_pair_kernel': 'stem_pool_pair', 'stem_pool_pair_persist_kernel': 'stem_pool_pair',
+            'prep_input_pair_kernel': 'prep_input_pair'}.get(k, k)
 
 
 def layer_group(name):
