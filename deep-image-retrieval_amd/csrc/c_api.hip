@@ -425,7 +425,7 @@ int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void
     a.Cout2 = P2;
     a.relu2 = relu1 ? 1 : 0;
     if (!conv_c3c1_admissible(a))
-        return fail(DIR_ERR_INVALID, "conv_c3c1: planes must be 64 or 128, and P2 = P (or 128 after 64)");
+        return fail(DIR_ERR_INVALID, "conv_c3c1: planes must be 64, 128 (P2 = P, or 128 after 64) or 256 (P2 = 256, B*H*W % 64 == 0)");
     if (((uintptr_t)t2 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)res & 15) || ((uintptr_t)y & 15) ||
         ((uintptr_t)w1 & 15) || ((uintptr_t)t1 & 15) || ((uintptr_t)bias3 & 15) || ((uintptr_t)bias1 & 15))
         return fail(DIR_ERR_INVALID, "conv_c3c1: tensors must be 16-byte aligned");

@@ -27,7 +27,7 @@
 //
 // conv1' consumes exactly the 16-bit values stored to HBM, so the result equals the two-kernel path up
 // to the fp32 summation order of the K halves.  Weights of layer3 (1 MB per seam) do not fit the 512 KB
-// register file: the seam there stays two kernels.
+// register file: that seam streams them from L2 through an LDS ring instead (conv_seam3.hip).
 #include "dir_common.h"
 #include "conv_igemm.h"
 
@@ -332,6 +332,7 @@ bool conv_c3c1_admissible(const ConvArgs& a) {
     // either a tensor (a.res) or - DS form, planes 64 - the 64-channel block input a.x2, whose
     // downsample weights are concatenated to a.w along K ([Cout][64 + 64]) and biases summed in a.bias
     const bool ds = a.x2 != nullptr;
+    if (a.Cin == 256) return conv_seam3_admissible(a);     // layer3: the streamed-weights form (conv_seam3.hip)
     return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
            (a.Cin == 64 || a.Cin == 128) && a.Cout == 4 * a.Cin && (ds ? (a.res == nullptr && a.Cin == 64 && a.Cin2 == 64)
                                                                        : a.res != nullptr) &&
@@ -356,6 +357,7 @@ static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
 }
 
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
+    if (a.Cin == 256) return conv_seam3_launch(a, dtype, stream);
     if (a.x2)
         return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, true>(a, stream) : launch_c3c1<FP16, 64, true>(a, stream);
     if (a.Cin == 128)

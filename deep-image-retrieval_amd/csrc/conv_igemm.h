@@ -81,6 +81,10 @@ bool conv1x1_ring_dual_admissible(const ConvArgs& a);   // the two-source form (
 hipError_t conv1x1_ring_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_wreg_admissible(const ConvArgs& a);
 hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+// the layer3 seam (planes 256): weights streamed from L2 through an LDS ring by loader waves (conv_seam3.hip); reached
+// through conv_c3c1_admissible / conv_c3c1_launch like the register-stationary forms
+bool conv_seam3_admissible(const ConvArgs& a);
+hipError_t conv_seam3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_c3c1_admissible(const ConvArgs& a);
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3s_admissible(const ConvArgs& a);

@@ -1,0 +1,380 @@
+// conv_seam3.hip — the seam between two layer3 bottlenecks (planes P = 256) in ONE kernel (gfx950):
+//
+//     out  = relu(conv3(t2) + bias3 + residual)     [M, 1024]   closes block b      (resnet.py:78-85)
+//     t1'  = relu(conv1'(out) + bias1)              [M,  256]   opens  block b + 1  (resnet.py:70-72)
+//
+// conv_c3c1.hip does this for layer1 / layer2 with both weight matrices stationary in registers.  Layer3's are 512 KB
+// each: they fit neither the register file nor LDS, so round 2 left this seam as two kernels (conv_wreg.hip 106 us +
+// conv_persist.hip 84.5 us at batch 32, 940 MB of HBM traffic: conv1' reads back the 268 MB conv3 has just written).
+// Round 3's probes removed the objection - L2 hits ride next to HBM misses nearly for free, and loader waves that ONLY
+// issue LDS-DMA keep a ring full while consumer waves ONLY multiply (conv_ring.hip) - so here the weights STREAM from
+// L2 through LDS once per 64-pixel tile, and `out` goes from the accumulators to HBM and, the same 16 bytes, into the
+// LDS tile that conv1' multiplies: 670 MB of HBM traffic per seam instead of 940.
+//
+// One persistent 8-wave workgroup per CU walks 64-pixel tiles.  Per tile the ring carries 33 slots of 32 KB:
+//     [T2]  then for each of the 8 chunks c of 128 conv3-output channels:  [A0(c)] [A1(c)] [B0(c)] [B1(c)]
+//   T2      the t2 tile, 64 px x 256 ch - the consumers copy it into registers (B fragments of their 32 pixels,
+//           64 VGPRs, reused by all 8 chunks) instead of multiplying
+//   A0, A1  W3 rows [128 c, 128 c + 128) x K half (128) - phase A:  acc = bias3 + W3_c . t2   (64 ch x 32 px per wave)
+//           after A1: + residual chunk (LDS, loader-fetched) -> ReLU -> pack -> HBM and the Y tile (LDS, B-operand layout)
+//   B0, B1  W1[:, 128 c + 64 kb ... + 64) - phase B:  acc1 += W1_chunk . Y   (128 ch x 32 px per wave, resident over
+//           the 8 chunks); after B1(7): + bias1 (initial value) -> ReLU -> pack -> HBM
+// waves 4-7  loaders: nothing but LDS-DMA (8 instructions each per slot, + 4 each for the residual chunk that travels
+//            with A0), two slots ahead, counted vmcnt over one kind of op
+// waves 0-3  consumers (pixel half pt = w & 1, channel half = w >> 1): LDS reads, MFMAs, 16-byte stores
+//            (v_permlane32_swap pairs the half-waves' pieces: conv_ring.hip's epilogue); no VMEM loads, no vmcnt waits
+// One s_barrier per slot is the hand-off in both directions (slot g landed / slot g - 1 is free); the Y tile and the
+// residual chunk are single buffers whose reuse distance is two barriers (see the comments at their uses).
+// LDS: 3 x 32 KB ring + 16 KB Y + 16 KB residual + 5 KB biases = 133 KB.
+// conv1' consumes exactly the 16-bit values stored to HBM: the result equals the two-kernel path up to fp32 summation
+// order.
+#include "dir_common.h"
+#include "conv_igemm.h"
+
+// Timing-only experiment builds (scripts/exp_abl.sh conv_seam3 DIR_SEAM3_ABL <bits>): phases compiled out - 1 = no weight
+// DMA, 2 = no t2 / residual DMA, 4 = no fragment reads / MFMAs, 8 = no epilogues, 16 = no global stores.  NOT valid convs.
+#ifndef DIR_SEAM3_ABL
+#define DIR_SEAM3_ABL 0
+#endif
+
+namespace dir {
+
+__device__ __forceinline__ void dma16m(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
+}
+
+template <class DT>
+__global__ void __launch_bounds__(512) conv_seam3_kernel(const ConvArgs a) {
+    constexpr int P = 256, C4 = 1024, BM = 64;
+    constexpr int SLOT = 32768, NSLOT = 3;
+    constexpr int Y_OFF = NSLOT * SLOT;
+    constexpr int RES_OFF = Y_OFF + 16384;
+    constexpr int BIAS_OFF = RES_OFF + 16384;
+    constexpr int NCH = C4 / 128;          // 8 chunks
+    constexpr int SPT = 1 + 4 * NCH;       // 33 slots per tile
+    typedef typename DT::frag_t frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const lbias3 = (float*)(smem + BIAS_OFF);
+    float* const lbias1 = lbias3 + C4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhi = lane >> 5;
+
+    const int ntiles = a.M / BM;
+    const int first = blockIdx.x;
+    if (first >= ntiles) return;
+    const int my_tiles = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * SPT;
+
+    for (int i = tid; i < C4; i += 512) lbias3[i] = a.bias[i];
+    if (tid < P) lbias1[tid] = a.bias2[tid];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the only VGPR-kind loads of the kernel
+    ring_barrier();
+
+    if (wave >= 4) {
+        // ================================ loaders =============================================================
+        const int lw = wave - 4;
+        const __amdgpu_buffer_rsrc_t rsrc_t2 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (uint32_t)((size_t)a.M * P * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_res =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (uint32_t)((size_t)a.M * C4 * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, C4 * P * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, P * C4 * 2, 0x00020000);
+        // Per-lane source offsets of this wave's 8 instructions (1 KiB of LDS each, lane-linear) per slot kind; the tile /
+        // chunk / K position rides in the scalar offset.  The XOR swizzles are applied on the SOURCE side.
+        uint32_t vT[8], vA[8], vB[8], vR[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lw * 8 + j;
+            {   // T2 tile: rows of 512 B (256 channels); instruction k = rows 2k, 2k + 1; chunk swizzle (row & 15) on the low 4 bits
+                const int row = 2 * k + (lane >> 5), s = lane & 31;
+                const int chunk = (s & 16) | ((s ^ row) & 15);
+                vT[j] = (uint32_t)((row * P + chunk * 8) * 2);
+            }
+            {   // A slot: 128 rows (output channels) of 256 B (128 K); instruction k = rows 4k .. 4k + 3
+                const int row = 4 * k + (lane >> 4), s = lane & 15;
+                const int chunk = s ^ (row & 15);
+                vA[j] = (uint32_t)((row * P + chunk * 8) * 2);
+            }
+            {   // B slot: 256 rows (conv1' output channels) of 128 B (64 K); instruction k = rows 8k .. 8k + 7
+                const int row = 8 * k + (lane >> 3), s = lane & 7;
+                const int chunk = s ^ ((row >> 1) & 7);
+                vB[j] = (uint32_t)((row * C4 + chunk * 8) * 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // residual chunk: 64 rows (pixels) of 256 B (128 channels); instruction k = rows 4k .. 4k + 3
+            const int k = lw * 4 + j;
+            const int row = 4 * k + (lane >> 4), s = lane & 15;
+            const int chunk = s ^ (row & 15);
+            vR[j] = (uint32_t)((row * C4 + chunk * 8) * 2);
+        }
+        int is_tile = first, is_s = 0, is_slot = 0;
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            char* dst = smem + is_slot * SLOT + lw * 8192;
+            const int m0 = is_tile * BM;
+            if (is_s == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (!(DIR_SEAM3_ABL & 2)) dma16m(rsrc_t2, dst + j * 1024, vT[j], m0 * (P * 2));
+            } else {
+                const int q = is_s - 1, c = q >> 2, ph = q & 3;
+                if (ph < 2) {
+                    if (ph == 0) {   // the residual chunk of c travels with (and BEFORE) A0(c): landed by the same wait
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (!(DIR_SEAM3_ABL & 2)) dma16m(rsrc_res, smem + RES_OFF + (lw * 4 + j) * 1024, vR[j], (m0 * C4 + 128 * c) * 2);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (!(DIR_SEAM3_ABL & 1)) dma16m(rsrc_w3, dst + j * 1024, vA[j], (128 * c * P + ph * 128) * 2);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (!(DIR_SEAM3_ABL & 1)) dma16m(rsrc_w1, dst + j * 1024, vB[j], (128 * c + 64 * (ph - 2)) * 2);
+                }
+            }
+            is_slot = is_slot + 1 == NSLOT ? 0 : is_slot + 1;
+            if (++is_s == SPT) {
+                is_s = 0;
+                is_tile += (int)gridDim.x;
+            }
+        };
+        issue_next();
+        if (total > 1) issue_next();
+        int s1 = 1;   // slot-in-tile index of step g + 1
+        for (int g = 0; g < total; ++g) {
+            // this wave's part of slot g has landed; the ops of slot g + 1 (8, or 12 with a residual chunk) may stay in
+            // flight.  Nothing but LDS-DMA ever enters this wave's queue, so the count is exact.
+            if (g + 1 >= total) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (s1 >= 1 && ((s1 - 1) & 3) == 0) {
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+            ring_barrier();   // hand-off g: slot g is complete; the consumers have left step g - 1
+            if (g + 2 < total) issue_next();
+            if (++s1 == SPT) s1 = 0;
+        }
+        return;
+    }
+
+    // ==================================== consumers ===========================================================
+    const int pt = wave & 1, half = wave >> 1;
+    const int p = pt * 32 + lrow;                 // this lane's pixel within the tile
+    const int psw = p & 15;
+    const uint32_t out_bytes = (uint32_t)((size_t)a.M * C4 * 2);
+    const uint32_t t1_bytes = (uint32_t)((size_t)a.M * P * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.y2, 0, t1_bytes, 0x00020000);
+    char* const ytile = smem + Y_OFF;
+    const char* const rtile = smem + RES_OFF;
+    Ovf<DT> ovf;
+    frag_t t2f[16];
+    f32x16_t acc[2], acc1[4];
+    int tile = first, slot = 0;
+    auto next_slot = [&]() { slot = slot + 1 == NSLOT ? 0 : slot + 1; };
+    // A fragment offsets inside a slot
+    const int a_row = (half * 64 + lrow) * 256;              // phase A: + i * 32 rows; chunk (2 ks + lhi) ^ (lrow & 15)
+    const int b_row = (half * 128 + lrow) * 128;             // phase B: + i * 32 rows; chunk (2 ks + lhi) ^ ((lrow >> 1) & 7)
+    const int a_sw = lrow & 15, b_sw = (lrow >> 1) & 7;
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int m0 = tile * BM;
+        // ---- T2: the tile's pixels into registers ----------------------------------------------------------------
+        ring_barrier();
+        {
+            const char* st = smem + slot * SLOT + p * 512;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int c5 = 2 * ks + lhi;
+                t2f[ks] = *(const frag_t*)(st + (((c5 & 16) | ((c5 ^ psw) & 15)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        next_slot();
+        for (int c = 0; c < NCH; ++c) {
+            // ---- phase A: acc = bias3 + W3_c . t2 -------------------------------------------------------------------
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                ring_barrier();
+                const char* st = smem + slot * SLOT + a_row;
+                if (kh == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const f32x4_t b4 = *(const f32x4_t*)(lbias3 + 128 * c + half * 64 + i * 32 + 8 * gg + 4 * lhi);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][4 * gg + e] = b4[e];
+                        }
+                }
+                if (!(DIR_SEAM3_ABL & 4)) {
+                frag_t wf[4][2];     // fragments four K-slices ahead: one wave per SIMD has nobody else to hide LDS latency
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        wf[ks][i] = *(const frag_t*)(st + i * (32 * 256) + (((2 * ks + lhi) ^ a_sw) << 4));
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = DT::mfma32(wf[ks & 3][i], t2f[kh * 8 + ks], acc[i]);
+                    if (ks + 4 < 8) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            wf[ks & 3][i] = *(const frag_t*)(st + i * (32 * 256) + (((2 * (ks + 4) + lhi) ^ a_sw) << 4));
+                    }
+                }
+                }
+                if (kh == 1 && !(DIR_SEAM3_ABL & 8)) {
+                    // ---- epilogue A: + residual (LDS) -> ReLU -> pack -> HBM + the Y tile ------------------------------
+                    // The residual chunk landed with slot A0(c) (two barriers ago); the Y tile was last read in step
+                    // B1(c - 1), two barriers ago.  Both are free to be overwritten two barriers from now.
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            uint32_t q2[2][2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int gg = 2 * h + q;
+                                // residual of channels 8 gg + 4 lhi .. + 3 of channel tile i: 8 bytes of 16-byte chunk
+                                // half * 8 + 4 i + gg of this pixel's row
+                                const u32x2_t r2 = *(const u32x2_t*)(rtile + p * 256 + (((half * 8 + 4 * i + gg) ^ psw) << 4) + lhi * 8);
+                                float r0, r1, r2f, r3;
+                                DT::unpack(r2[0], r0, r1);
+                                DT::unpack(r2[1], r2f, r3);
+                                float v[4] = {acc[i][4 * gg + 0] + r0, acc[i][4 * gg + 1] + r1, acc[i][4 * gg + 2] + r2f,
+                                              acc[i][4 * gg + 3] + r3};
+                                if (a.relu) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                                }
+                                q2[q][0] = DT::pack(v[0], v[1]);
+                                q2[q][1] = DT::pack(v[2], v[3]);
+                            }
+                            // lanes 0-31 end up with channels 16 h .. 16 h + 7 of pixel lrow, lanes 32-63 with the next eight
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
+                            const u32x4_t ov = {s0[0], s1[0], s0[1], s1[1]};
+                            const int chn = half * 64 + i * 32 + h * 16 + lhi * 8;      // channel within the chunk
+                            ovf.see(ov);
+                            *(u32x4_t*)(ytile + p * 256 + ((((chn >> 3)) ^ psw) << 4)) = ov;
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                next_slot();
+            }
+            // ---- phase B: acc1 += W1[:, chunk c] . Y ---------------------------------------------------------------------
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                ring_barrier();
+                const char* st = smem + slot * SLOT + b_row;
+                if (kb == 0 && !(DIR_SEAM3_ABL & 16)) {
+                    // `out` goes to HBM from the Y tile, not from the accumulators: a wave's 16-byte pieces there are 32
+                    // scattered 32-byte segments per store instruction (one pixel row per lane pair), which held the
+                    // consumers at issue for 70 of 196 us; from the tile, 16 lanes cover one pixel's 256 contiguous bytes
+                    // (4 rows per instruction).  Wave w copies rows 16 w .. 16 w + 15; the stores drain under the MFMAs.
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 16 * wave + 4 * j + (lane >> 4), sl = lane & 15;
+                        const u32x4_t ov = *(const u32x4_t*)(ytile + r * 256 + sl * 16);
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, (uint32_t)(((m0 + r) * C4 + 128 * c + ((sl ^ (r & 15)) << 3)) * 2), 0, 0);
+                    }
+                }
+                if (c == 0 && kb == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const f32x4_t b4 = *(const f32x4_t*)(lbias1 + half * 128 + i * 32 + 8 * gg + 4 * lhi);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc1[i][4 * gg + e] = b4[e];
+                        }
+                }
+                if (!(DIR_SEAM3_ABL & 4)) {
+                frag_t wb[2][4], yb[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wb[ks][i] = *(const frag_t*)(st + i * (32 * 128) + (((2 * ks + lhi) ^ b_sw) << 4));
+                    yb[ks] = *(const frag_t*)(ytile + p * 256 + (((kb * 8 + 2 * ks + lhi) ^ psw) << 4));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc1[i] = DT::mfma32(wb[ks & 1][i], yb[ks & 1], acc1[i]);
+                    if (ks + 2 < 4) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            wb[ks & 1][i] = *(const frag_t*)(st + i * (32 * 128) + (((2 * (ks + 2) + lhi) ^ b_sw) << 4));
+                        yb[ks & 1] = *(const frag_t*)(ytile + p * 256 + (((kb * 8 + 2 * (ks + 2) + lhi) ^ psw) << 4));
+                    }
+                }
+                }
+                if (c == NCH - 1 && kb == 1 && !(DIR_SEAM3_ABL & 8)) {
+                    // ---- epilogue B: ReLU -> pack -> HBM (the bias was the accumulators' initial value) -----------------
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            uint32_t q2[2][2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int gg = 2 * h + q;
+                                float v[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float x = acc1[i][4 * gg + e];
+                                    v[e] = a.relu2 ? fmaxf(x, 0.f) : x;
+                                }
+                                q2[q][0] = DT::pack(v[0], v[1]);
+                                q2[q][1] = DT::pack(v[2], v[3]);
+                            }
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(q2[0][0], q2[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(q2[0][1], q2[1][1], false, false);
+                            const u32x4_t ov = {s0[0], s1[0], s0[1], s1[1]};
+                            const int chn = half * 128 + i * 32 + h * 16 + lhi * 8;
+                            if (!(DIR_SEAM3_ABL & 16))
+                                __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y2, (uint32_t)(((m0 + p) * P + chn) * 2), 0, 0);
+                            ovf.see(ov);
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                next_slot();
+            }
+        }
+        tile += (int)gridDim.x;
+    }
+    ovf.flush(a.ovf);
+}
+
+bool conv_seam3_admissible(const ConvArgs& a) {
+    return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW && a.Cin == 256 &&
+           a.Cout == 1024 && a.Cout2 == 256 && a.res != nullptr && a.x2 == nullptr && a.w2 != nullptr && a.bias2 != nullptr &&
+           a.y2 != nullptr && a.M % 64 == 0 && (long)a.M * a.Cout < (1L << 30);
+}
+
+template <class DT>
+static hipError_t launch_seam3(const ConvArgs& a, hipStream_t stream) {
+    constexpr int LDS = 3 * 32768 + 16384 + 16384 + (1024 + 256) * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv_seam3_kernel<DT>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
+    const int nt = a.M / 64;
+    const int ncu = cu_count();
+    hipLaunchKernelGGL(kern, dim3(nt < ncu ? nt : ncu), dim3(512), LDS, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t conv_seam3_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
+    return dtype == DIR_BF16 ? launch_seam3<BF16>(a, stream) : launch_seam3<FP16>(a, stream);
+}
+
+}  // namespace dir

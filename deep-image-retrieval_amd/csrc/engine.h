@@ -120,7 +120,7 @@ struct dir_engine {
     // A/B switches, read from the environment ONCE per forward() (tests toggle them between calls; a getenv
     // per block would cost tens of microseconds of a 1.5 ms batch-1 step)
     struct Switches {
-        bool c3c1_off = false, c3c1_force = false, no_ds_seam = false, no_dual = false, rev_conv1 = false, rev_conv3 = false;
+        bool c3c1_off = false, c3c1_force = false, no_ds_seam = false, no_dual = false, no_seam3 = false, rev_conv1 = false, rev_conv3 = false;
     } sw;
     float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,

@@ -691,6 +691,7 @@ int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt,
 // about 8 pixel tiles of 64 per workgroup (A/B at 1024^2: batch 1 = 1024 tiles: -2 %, batch 2: equal, batch 4:
 // +4 %, batch 32: +6 %).
 static constexpr long kSeamMinTiles = 2048;
+static constexpr long kSeam3MinTiles = 768;   // conv_seam3.hip: three 64-pixel tiles per CU
 
 int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
                          uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
@@ -734,7 +735,9 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     a.ovf = d_ovf;
     if (c1.R != 1 || c1.S != 1 || c1.stride != 1 || c1.pad != 0 || c1.Cin != c3.Cout || !conv_c3c1_admissible(a))
         return DIR_OK;
-    if (!sw.c3c1_force && (a.M + 63) / 64 < kSeamMinTiles) return DIR_OK;
+    // (the layer3 form streams its weights per tile anyway: it only needs a few tiles per persistent workgroup)
+    if (!sw.c3c1_force && (a.M + 63) / 64 < (a.Cin == 256 ? kSeam3MinTiles : kSeamMinTiles)) return DIR_OK;
+    if (a.Cin == 256 && sw.no_seam3) return DIR_OK;
     const double macs = (double)a.M * ((double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
     const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
                                 (double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
@@ -742,7 +745,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     int rc = DIR_OK;
     if (profiling && !prof_paused)
         rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + (block_in ? ".ds+c3c1" : ".c3c1"),
-                        "conv_c3c1<" + std::to_string(c3.Cin) + (block_in ? ",ds>" : ">"),
+                        (c3.Cin == 256 ? "conv_seam3<" : "conv_c3c1<") + std::to_string(c3.Cin) + (block_in ? ",ds>" : ">"),
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     hipError_t e = conv_c3c1_launch(a, kdtype(), stream);
@@ -814,6 +817,9 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         sw.c3c1_force = mode && mode[0] == 'f';
         sw.no_ds_seam = getenv("DIRTORCH_AMD_NO_DS_SEAM") != nullptr;
         sw.no_dual = getenv("DIRTORCH_AMD_NO_DUAL") != nullptr;
+        // conv_seam3.hip (layer3's conv3 -> conv1 in one kernel) is correct and tested but LOSES to the two kernels it
+        // replaces (245 vs 203 us at batch 32: profiles/r04_seam3_ablation.txt) - opt-in, for A/B: DIRTORCH_AMD_SEAM3=1
+        sw.no_seam3 = getenv("DIRTORCH_AMD_SEAM3") == nullptr;
         sw.rev_conv1 = getenv("DIRTORCH_AMD_REV_CONV1") != nullptr;
         sw.rev_conv3 = getenv("DIRTORCH_AMD_REV_CONV3") != nullptr;
     }

@@ -623,6 +623,43 @@ def test_fused_seam_vs_oracle_and_two_kernel_path(B, H, W, P, P2, dname, relu3):
     assert torch.equal(y, y2) and torch.equal(t1, t12)
 
 
+# the layer3 form (conv_seam3.hip: planes 256, weights streamed through an LDS ring by loader waves): pixel counts that
+# are multiples of 64 - one tile; fewer tiles than CUs; 400 tiles on 256 persistent workgroups (one or two each); 1024
+# tiles (four each: the ring runs across tile boundaries, residual / Y buffers are reused 32 times)
+SEAM3_SHAPES = [(1, 8, 8), (2, 32, 32), (4, 80, 80), (4, 128, 128)]
+
+
+@pytest.mark.parametrize('relu3', [True, False])
+@pytest.mark.parametrize('dname', ['bf16', 'fp16'])
+@pytest.mark.parametrize('B,H,W', SEAM3_SHAPES)
+def test_layer3_seam_vs_oracle_and_two_kernel_path(B, H, W, dname, relu3):
+    """dir_conv_c3c1 at planes 256 (conv_seam3.hip) against the fp32 CPU oracle of both convolutions on the same
+    rounded operands and against the two dir_conv_bn_act launches it replaces, run on the fused kernel's own block
+    output; run-to-run identical."""
+    ops = _ops()
+    dt = DTYPES[dname]
+    P = 256
+    t2 = F.relu(_rand((B, H, W, P), 1)).to(dt)
+    w3 = _rand((4 * P, 1, 1, P), 2, (2.0 / P) ** 0.5).to(dt)
+    b3 = _rand((4 * P,), 3, 0.2)
+    res = F.relu(_rand((B, H, W, 4 * P), 4)).to(dt)
+    w1 = _rand((P, 1, 1, 4 * P), 5, (2.0 / (4 * P)) ** 0.5).to(dt)
+    b1 = _rand((P,), 6, 0.2)
+    y, t1 = ops.conv_c3c1(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), w1.cuda(), b1.cuda(), relu3=relu3, relu1=True)
+    torch.cuda.synchronize()
+    y_two = ops.conv_bn_act(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), relu=relu3)
+    check_close(y, y_two.float().cpu(), dname, 'layer3 seam vs two-kernel conv3')
+    t1_two = ops.conv_bn_act(y, w1.cuda(), b1.cuda(), None, relu=True)
+    check_close(t1, t1_two.float().cpu(), dname, 'layer3 seam vs two-kernel conv1')
+    if B * H * W <= 25600:      # (the CPU oracle of the big case is the two-kernel path's own test)
+        ref_y = conv_reference(t2, w3, b3, res, 1, 0, relu3)
+        check_close(y, ref_y, dname, 'layer3 seam: block output')
+        ref_t1 = conv_reference(y.cpu(), w1, b1, None, 1, 0, True)
+        check_close(t1, ref_t1, dname, 'layer3 seam: next conv1')
+    y2, t12 = ops.conv_c3c1(t2.cuda(), w3.cuda(), b3.cuda(), res.cuda(), w1.cuda(), b1.cuda(), relu3=relu3, relu1=True)
+    assert torch.equal(y, y2) and torch.equal(t1, t12)
+
+
 @pytest.mark.parametrize('dname', ['bf16', 'fp16'])
 @pytest.mark.parametrize('B,H,W', SEAM_SHAPES)
 def test_fused_seam_with_downsample_as_extra_k(B, H, W, dname):
@@ -688,9 +725,16 @@ def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2
 def test_fused_seam_argument_errors():
     from dirtorch_amd import _lib
     ops = _ops()
-    t2 = torch.zeros(1, 8, 8, 256, dtype=torch.bfloat16, device='cuda')      # planes 256: weights do not fit registers
+    t2 = torch.zeros(1, 8, 8, 512, dtype=torch.bfloat16, device='cuda')      # planes 512 (layer4): no fused form
+    w3 = torch.zeros(2048, 1, 1, 512, dtype=torch.bfloat16, device='cuda')
+    res = torch.zeros(1, 8, 8, 2048, dtype=torch.bfloat16, device='cuda')
+    w1 = torch.zeros(512, 1, 1, 2048, dtype=torch.bfloat16, device='cuda')
+    with pytest.raises(_lib.DirError):
+        ops.conv_c3c1(t2, w3, torch.zeros(2048, device='cuda'), res, w1, torch.zeros(512, device='cuda'))
+    # planes 256 (conv_seam3.hip) takes whole 64-pixel tiles only
+    t2 = torch.zeros(1, 5, 7, 256, dtype=torch.bfloat16, device='cuda')
     w3 = torch.zeros(1024, 1, 1, 256, dtype=torch.bfloat16, device='cuda')
-    res = torch.zeros(1, 8, 8, 1024, dtype=torch.bfloat16, device='cuda')
+    res = torch.zeros(1, 5, 7, 1024, dtype=torch.bfloat16, device='cuda')
     w1 = torch.zeros(256, 1, 1, 1024, dtype=torch.bfloat16, device='cuda')
     with pytest.raises(_lib.DirError):
         ops.conv_c3c1(t2, w3, torch.zeros(1024, device='cuda'), res, w1, torch.zeros(256, device='cuda'))
