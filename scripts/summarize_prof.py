@@ -65,6 +65,9 @@ def short(name):
     m = re.search(r'conv_c3c1_kernel<dir::(\w+), (\d+), (\w+), (\d+)>', name)
     if m:
         return 'conv_c3c1<%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv_seam3_kernel<dir::(\w+)>', name)
+    if m:   # the layer3 seam (csrc/conv_seam3.hip), opt-in
+        return 'conv_seam3<256>[%s]' % m.group(1).lower()
     m = re.search(r'conv_patch64_lc_kernel<dir::(\w+)>', name)
     if m:
         return 'conv_igemm<256x64_patchlc3x3>[%s]' % m.group(1).lower()
@@ -148,7 +151,7 @@ def pmc(fd, wd, out, traffic=None):
 
 
 # ---- per-kernel roofline table ---------------------------------------------------------------------
-ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'conv_f32<', 'conv_pair<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
+ENGINE_PREFIX = ('conv_igemm<', 'conv_c3c1<', 'conv_seam3<', 'conv_f32<', 'conv_pair<', 'stem_pool', 'prep_input', 'global_pool', 'gemm_nt', 'maxpool', 'upsample_add')
 PEAK_TF, PEAK_GBS, NXCC, NSIMD = 2500.0, 8000.0, 8, 1024
 FOLLOW_UP = ('gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel')
 MEASURED_TF, MEASURED_GBS = 1582.0, 6305.0   # scripts/probes/*_ceiling.hip on a pool box (profiles/r02_*_ceiling.txt)
