@@ -201,6 +201,36 @@ def precision_leg(arch, size, batch, x_bench, cpu_seconds):
     return out, cpu
 
 
+def other_workloads(args, x_bench):
+    """BASELINE configs[3] and configs[4] on one GPU, bounded to a few seconds, for the driver's one line: the
+    distractor protocol (70 x 1 006 322 x 2048 similarity + device rank / AP) and the three-scale extraction of
+    1200^2 images.  Same code as --workload distractors / multiscale, fewer steps; failures are reported, not raised
+    (the headline number is already measured)."""
+    import copy
+    out = {}
+    del x_bench
+    torch.cuda.empty_cache()
+    for name, fn, over in (('distractors', bench_distractors, {'steps': 5, 'warmup': 2, 'cpu_seconds': 0.0}),
+                           ('multiscale', bench_multiscale, {'steps': 3, 'warmup': 2})):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            r = fn(a, 1, 0, None)
+            if name == 'distractors':
+                out[name] = {'db_rows': a.db_rows, 'queries': a.queries, 'ms_per_step': r['ms_per_step'],
+                             'db_rows_per_sec': r['value'], 'sim_ms': r['roofline']['avg_launch_ms'],
+                             'sim_hbm_frac': r['roofline']['frac'], 'rank_ap_ms': r['roofline']['rank_ap_ms'],
+                             'mAP_medium': r['config']['mAP_medium']}
+            else:
+                out[name] = {'images_per_sec_3scale': r['value'], 'ms_per_step': r['ms_per_step'], 'batch': a.ms_batch,
+                             'size': a.ms_size, 'step_mfma_frac': r['roofline']['frac'], 'dtype': r['dtype']}
+        except Exception as e:      # noqa: BLE001 - report and go on
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
+
+
 def layer_group(name):
     """'layer3.7.conv2' -> 'layer3.conv2' (the identical blocks 1.. of a stage share a row); block 0 of a
     stage differs in shape (stride / input width) and keeps its own name 'layer3.0.conv2'."""
@@ -285,7 +315,6 @@ def bench_distractors(args, world, rank, dist):
         db.hard.append(sorted(idx[80:160].tolist()))
         db.junk.append(sorted(idx[160:].tolist()))
     tables = ranking.build_probe_tables(db)
-    sizes = [ddist.shard_range(N, r_, world) for r_ in range(world)]
     full = torch.empty(world * rows, D, device='cuda') if args.exchange == 'descriptors' and world > 1 else None
     sc_all = torch.empty(world, Q, rows, device='cuda') if args.exchange == 'scores' and world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -299,19 +328,16 @@ def bench_distractors(args, world, rank, dist):
                 dist.all_gather_into_tensor(full, local)              # the one exchange step (RCCL over xGMI)
             if record:
                 ev[1].record()
-            if world > 1 and rows * world != N:
-                # shards of unequal length arrive padded: score block by block instead of compacting 8 GB
-                scores = torch.cat([ops.similarity(qs, full[r_ * rows:r_ * rows + (h - l)])
-                                    for r_, (l, h) in enumerate(sizes)], dim=1)
-            else:
-                scores = ops.similarity(qs, full if world > 1 else local[:N])
+            # (shards of unequal length - 1 006 322 % 8 = 2 - arrive padded and are scored block by block:
+            # dirtorch_amd.distributed.score_gathered, tests/test_ranking_gpu.py::test_sharded_scoring_*)
+            scores = ddist.score_gathered(qs, full, N, world, ops.similarity) if world > 1 else ops.similarity(qs, local[:N])
         else:
             mine = ops.similarity(qs, local)                          # [Q, rows] (padding rows score 0)
             if record:
                 ev[1].record()
             if world > 1:
                 dist.all_gather_into_tensor(sc_all, mine)
-                scores = torch.cat([sc_all[r_, :, :h - l] for r_, (l, h) in enumerate(sizes)], dim=1).contiguous()
+                scores = ddist.merge_score_blocks(sc_all, N, world)
             else:
                 scores = mine[:, :N].contiguous()
         if record:
@@ -347,7 +373,7 @@ def bench_distractors(args, world, rank, dist):
     for _ in range(3):      # per-phase durations (events on torch's current stream, where every kernel above runs)
         step(True)
     if rank != 0:
-        return
+        return None
     mean = lambda v: sum(v) / len(v) if v else 0.0   # noqa: E731
     sim_ms, x_ms, r_ms = mean(t_s), mean(t_x), mean(t_r)
     sim_rows = N if args.exchange == 'descriptors' else rows
@@ -361,6 +387,7 @@ def bench_distractors(args, world, rank, dist):
         'config': {'workload': 'configs[3]: RParis6K + 1M synthetic distractors (N = %d unit-norm 2048-d rows, Q = %d), '
                                'database sharded over the ranks, one all-gather of %s, similarity + device rank/AP'
                                % (N, Q, 'descriptor blocks' if args.exchange == 'descriptors' else 'score blocks'),
+                   'rccl_ranks': dist.get_world_size() if dist is not None else 0,
                    'exchange': args.exchange, 'rows_per_rank': rows, 'mAP_medium': round(float(np.mean([a['medium'] for a in aps])), 6)},
         'roofline': {'bound': 'hbm', 'kernel': ('sim_split_kernel' if os.environ.get('DIRTORCH_AMD_SIM_V1') else 'sim_split_lc_kernel') if sim_rows >= 32768 else 'gemm_nt_f32',
                      'achieved': round(sim_bytes / (sim_ms * 1e-3) / 1e9, 1) if sim_ms else None, 'peak': PEAK_HBM_GBS,
@@ -386,7 +413,7 @@ def bench_distractors(args, world, rank, dist):
         dt = time.perf_counter() - t0
         out['cpu_baseline'] = {'value': round(n / dt, 1), 'unit': 'db_rows/sec', 'cores': torch.get_num_threads(),
                                'kind': 'port', 'sample': 'np.dot(Q x D, D x %d) + 3 argsorts per query (%.2f s)' % (n, dt)}
-    print(json.dumps(out))
+    return out
 
 
 def bench_multiscale(args, world, rank, dist):
@@ -437,24 +464,25 @@ def bench_multiscale(args, world, rank, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     if rank != 0:
-        return
+        return None
     # ResNet-101 trunk: 448.76 GFLOP at 1200^2, quadratic in the side
     gflop = sum(448.76 * (s_[0] * s_[1]) / (1200.0 * 1200.0) for s_ in sizes)
     ips = world * K * B / el
-    print(json.dumps({
+    return ({
         'metric': 'images/sec 3-scale descriptor extraction (%s-GeM, %dx%d, scales 0.7071/1/1.4142)' % (args.arch, S, S),
         'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
         'ms_per_step': round(el / K * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'fp16', 'data': 'synthetic',
         'config': {'workload': 'configs[4]: %s-GeM multi-scale (3 scales %s) extraction of %dx%d uint8 images, fp16, '
                                'image-parallel, one all-gather of descriptor blocks' % (args.arch, [s_[0] for s_ in sizes], S, S),
-                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim)},
+                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim),
+                   'rccl_ranks': dist.get_world_size() if dist is not None else 0},
         'roofline': {'bound': 'mfma', 'kernel': 'whole step (three dir_forward passes + resize + pooling)',
                      'achieved': round(ips / world * gflop / 1e3, 1), 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s',
                      'frac': round(ips / world * gflop / 1e3 / PEAK_TFLOPS['fp16'], 4), 'traffic': None,
                      'note': 'step-level figure: conv FLOPs of the three scales / step time; the per-kernel table is the '
                              'extract workload\'s (same kernels, same layer shapes at 1024^2)'},
-        'cpu_baseline': None}))
+        'cpu_baseline': None})
 
 
 def main():
@@ -473,6 +501,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU legs (baseline + precision)')
     ap.add_argument('--no-precision', action='store_true',
                     help='skip the fp16 / strict-fp32 throughput and the parity-vs-oracle fields (config.precision)')
+    ap.add_argument('--no-workloads', action='store_true',
+                    help='skip the bounded configs[3] / configs[4] runs that fill config.workloads')
     ap.add_argument('--workload', default='extract', choices=['extract', 'distractors', 'multiscale'],
                     help="extract = BASELINE configs[1] (default); multiscale = configs[4] (3 scales of 1200^2, fp16); distractors = configs[3]: a database of --db-rows "
                          "2048-d descriptors sharded over the ranks, ONE all-gather, Q x N similarity, device rank + AP")
@@ -506,7 +536,9 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
 
     if args.workload in ('distractors', 'multiscale'):
-        (bench_distractors if args.workload == 'distractors' else bench_multiscale)(args, world, rank, dist)
+        out = (bench_distractors if args.workload == 'distractors' else bench_multiscale)(args, world, rank, dist)
+        if out is not None:
+            print(json.dumps(out))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -638,7 +670,7 @@ def main():
                 ms /= n
                 print('%-24s %-36s %8.3f ms %8.1f TF/s %8.1f GB/s' % (
                     name, kern, ms, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
-        cpu, precision = None, None
+        cpu, precision, workloads = None, None, None
         if world == 1 and args.cpu_seconds > 0:
             del shard
             net._ws = {}
@@ -647,6 +679,8 @@ def main():
                 cpu, _ = cpu_baseline(args.arch, S, args.cpu_seconds)
             else:
                 precision, cpu = precision_leg(args.arch, S, B, x, args.cpu_seconds)
+            if not args.no_workloads:
+                workloads = other_workloads(args, x)
         value = world * B * K / el
         out = {
             'metric': 'images/sec descriptor extraction (%s-GeM, %dx%d)' % (args.arch, S, S),
@@ -661,7 +695,11 @@ def main():
                        'parallelism': 'image-parallel shards, 1 all-gather of descriptors' if world > 1 else 'single GPU',
                        # the other storage formats on the same step, and what each loses against the fp32 CPU
                        # oracle (descriptors at the bench size + mAP through whitening / similarity / AP)
-                       'precision': precision},
+                       'precision': precision,
+                       # BASELINE configs[3] / configs[4] on this GPU, a few steps each outside the timed region
+                       # (the full lines: --workload distractors / multiscale)
+                       'workloads': workloads,
+                       'rccl_ranks': dist.get_world_size() if dist is not None else 0},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(out))

@@ -133,6 +133,8 @@ int dir_conv_bn_act_f32(const float* x, const float* w, const float* bias, const
                         void* stream) {
     DIR_TRY
     if (!x || !w || !bias || !y) return fail(DIR_ERR_INVALID, "conv_bn_act_f32: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0)
+        return fail(DIR_ERR_INVALID, "conv_bn_act_f32: bad dimension");     // (before the geometry check divides by stride)
     if (OH != (H + 2 * pad - R) / stride + 1 || OW != (W + 2 * pad - S) / stride + 1)
         return fail(DIR_ERR_INVALID, "conv_bn_act_f32: OH/OW do not match the conv geometry");
     ConvF32Args a;

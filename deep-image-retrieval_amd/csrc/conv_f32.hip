@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) conv_f32_kernel(const ConvF32Args a) {
                 if (a.res) v = v + *(const DIR_GLOBAL f32x4_t*)(a.res + o);
                 if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // torch's relu: a NaN stays a NaN (fmaxf would flush it)
                 }
                 *(DIR_GLOBAL f32x4_t*)(a.y + o) = v;
             }

@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         }
         ring_barrier();
         if (issued < T) {
-#ifndef DIR_EXP_NO_FILL     // experiment builds (scripts/exp_fill.sh): MFMA + fragment reads alone
+#ifndef DIR_EXP_NO_FILL     // experiment builds (scripts/exp_abl.sh conv_igemm DIR_EXP_NO_FILL 1): MFMA + fragment reads alone
             issue(wstep_now(), tap, koff_now(), smem + slot_i * STAGE_BYTES);
 #endif
             advance();

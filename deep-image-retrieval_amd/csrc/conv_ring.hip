@@ -46,7 +46,7 @@
 #include "dir_common.h"
 #include "conv_igemm.h"
 
-// Timing-only experiment builds (scripts/exp_ring.sh): -DDIR_RING_ABL=<bits> compiles phases out - 1 = no pixel DMA,
+// Timing-only experiment builds (scripts/exp_abl.sh conv_ring DIR_RING_ABL <bits>): -DDIR_RING_ABL=<bits> compiles phases out - 1 = no pixel DMA,
 // 2 = no weight DMA, 4 = no fragment reads / MFMAs, 8 = no epilogue.  Results are NOT valid convolutions.
 #ifndef DIR_RING_ABL
 #define DIR_RING_ABL 0

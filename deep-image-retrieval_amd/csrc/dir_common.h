@@ -163,7 +163,7 @@ struct Ovf {
 // fence the scheduler honours (CDNA guide, section 5.4 rule 18); tests/test_isa_audit.py checks the emitted code of
 // every ring kernel for LDS reads that cross a barrier into an MFMA.
 __device__ __forceinline__ void ring_barrier() {
-#ifndef DIR_EXP_NO_RING_FENCE   // experiment builds only (scripts/exp_fence.sh): what the two fences cost
+#ifndef DIR_EXP_NO_RING_FENCE   // experiment builds only (scripts/exp_abl.sh all DIR_EXP_NO_RING_FENCE 1): what the two fences cost
     __builtin_amdgcn_sched_barrier(0);
 #endif
     __builtin_amdgcn_s_barrier();

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(512) sim_split_kernel(const float* __restrict_
     }
 }
 
-// Timing-only experiment builds (scripts/exp_sim.sh): -DDIR_SIM_ABL=<bits> - 1 = no database DMA, 2 = no query DMA,
+// Timing-only experiment builds (scripts/exp_abl.sh sim_split DIR_SIM_ABL <bits>): -DDIR_SIM_ABL=<bits> - 1 = no database DMA, 2 = no query DMA,
 // 4 = consumers only take the barriers.  Results are NOT valid scores.
 #ifndef DIR_SIM_ABL
 #define DIR_SIM_ABL 0

@@ -50,6 +50,37 @@ def shard_range(n, r=None, w=None):
     return (r * n) // w, ((r + 1) * n) // w
 
 
+def shard_sizes(n, w=None):
+    """[(lo, hi)] of every rank's contiguous range."""
+    w = world_size() if w is None else w
+    return [shard_range(n, r, w) for r in range(w)]
+
+
+def padded_rows(n, w=None):
+    """Rows of the common (padded) block the collective exchanges: the longest shard."""
+    return max(h - l for l, h in shard_sizes(n, w))
+
+
+def score_gathered(queries, gathered, n_total, w, similarity):
+    """Scores [Q, n_total] of `queries` against a database that arrived through ONE all_gather_into_tensor of padded
+    shard blocks: `gathered` is [w * rows, D] with shard r at rows [r * rows, r * rows + n_r).  Equal shards: one
+    similarity call over the whole buffer.  Unequal shards (n_total % w != 0 - e.g. 1 006 322 rows on 8 GPUs): the
+    padding rows sit BETWEEN the shards, so each block is scored on its own and the [Q, n_r] pieces are concatenated -
+    no 8 GB compaction copy.  similarity(queries, block) -> [Q, rows of block] (dirtorch_amd.ops.similarity)."""
+    rows = padded_rows(n_total, w)
+    assert gathered.shape[0] == w * rows, (gathered.shape, w, rows)
+    if rows * w == n_total:
+        return similarity(queries, gathered)
+    return torch.cat([similarity(queries, gathered[r * rows:r * rows + (h - l)])
+                      for r, (l, h) in enumerate(shard_sizes(n_total, w))], dim=1)
+
+
+def merge_score_blocks(score_blocks, n_total, w):
+    """The cheaper exchange: every rank scored only its own (padded) rows, the [w, Q, rows] score blocks were
+    all-gathered; trims every block's padding columns and concatenates in dataset order -> [Q, n_total]."""
+    return torch.cat([score_blocks[r, :, :h - l] for r, (l, h) in enumerate(shard_sizes(n_total, w))], dim=1).contiguous()
+
+
 def allgather_rows(local, n_total):
     """local: this rank's [hi-lo, D] block (rows shard_range(n_total)) -> the full [n_total, D]
     on every rank, in dataset order.  One collective."""
@@ -108,15 +139,17 @@ def extract_sharded(extract_fn, dataset, trfs, net, width=None, **kw):
     if hi > lo:
         try:
             local = extract_fn(SubDataset(dataset, lo, hi), trfs, net, **kw)
-        except FloatingPointError as e:     # (fp16 overflow on this rank's shard, test_dir._check_finite)
+        except Exception as e:     # fp16 overflow on this rank's shard (test_dir._check_finite), a DirError, an OOM ...
             err = e
-    if local is None:
-        local = torch.zeros((hi - lo if err else 0, D), dtype=torch.float32, device=dev)
     # every rank must reach the collective: a rank that raised on its own would leave the others blocked in
-    # the all-gather until the RCCL timeout.  Agree on the failure first, then raise everywhere.
+    # the all-gather until the RCCL timeout.  Agree on the failure first (ANY exception), then raise everywhere.
     bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=dev)
     torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
     if int(bad.item()):
-        raise err if err else FloatingPointError('another rank reported non-finite descriptors / fp16 overflow '
-                                                 'on its shard (see its log); run with DIRTORCH_AMD_DTYPE=bf16')
+        if err:
+            raise err
+        raise FloatingPointError('another rank failed on its shard (see its log: non-finite descriptors / fp16 overflow, '
+                                 'an engine error or out of memory); for an overflow run with DIRTORCH_AMD_DTYPE=bf16')
+    if local is None:      # an empty shard (more ranks than images)
+        local = torch.zeros((0, D), dtype=torch.float32, device=dev)
     return allgather_rows(local, n)

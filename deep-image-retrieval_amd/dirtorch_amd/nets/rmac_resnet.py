@@ -56,6 +56,7 @@ class ResNet_RMAC(object):
     """ResNet trunk + global pooling + FC + L2 (without ROI pooling), engine-backed."""
 
     HEAD = _lib.DIR_HEAD_RMAC      # dir_head of include/dir_engine.h
+    MAX_WORKSPACES = 6             # one per HIP stream in use (the current one + test_dir.StreamPool's four), LRU beyond
     SQUEEZE = True                 # x.squeeze_() before the FC (rmac_resnet.py:64): [D] at B == 1
 
     def __init__(self, model_name, out_dim=2048, norm_features=False, pooling='gem', gemp=3,
@@ -263,12 +264,13 @@ class ResNet_RMAC(object):
         # few images that way - a single 1024^2 image cannot fill 256 CUs) must not share scratch; on one stream
         # successive forwards are ordered, so they can
         key = torch.cuda.current_stream().cuda_stream
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)            # (re-inserted below: the dict is kept in least-recently-used order)
         if ws is None or ws.numel() < need.value:
-            self._ws.pop(key, None)
             del ws
+            while len(self._ws) >= self.MAX_WORKSPACES:      # streams nobody has used for a while give theirs back
+                self._ws.pop(next(iter(self._ws)))
             ws = torch.empty(need.value, dtype=torch.uint8, device='cuda')
-            self._ws[key] = ws
+        self._ws[key] = ws
         return ws
 
     def _prepare(self, x):
@@ -360,6 +362,7 @@ class ResNet_RMAC(object):
         if self._dirty or self._engine is None:
             self._build_engine()
         call('dir_engine_set_profiling', self._engine, int(enabled))
+        self._profiling = bool(enabled)      # (test_dir.StreamPool keeps to one stream while records are being taken)
 
     def pause_profiling(self, paused):
         call('dir_engine_profile_pause', self._engine, int(bool(paused)))

@@ -59,11 +59,15 @@ def _check_finite(feats, net):
     and the descriptors themselves (inf / NaN weights in the checkpoint show up here in any dtype)."""
     overflow = getattr(net, 'overflowed', lambda: False)()
     if overflow or (feats.numel() and not bool(torch.isfinite(feats).all())):
-        raise FloatingPointError('%s with compute dtype %s: activations left the 16-bit range; run with '
-                                 'DIRTORCH_AMD_DTYPE=bf16 (fp32 range, 8-bit mantissa) or DIRTORCH_AMD_DTYPE=f32 '
-                                 '(the reference\'s arithmetic)'
-                                 % ('fp16 overflow inside the trunk' if overflow else 'non-finite descriptors',
-                                    getattr(net, 'compute_dtype', '?')))
+        dtype = getattr(net, 'compute_dtype', '?')
+        if overflow or dtype in ('fp16', 'fp16p'):
+            raise FloatingPointError('%s with compute dtype %s: activations left the fp16 range; run with '
+                                     'DIRTORCH_AMD_DTYPE=bf16 (fp32 range, 8-bit mantissa) or DIRTORCH_AMD_DTYPE=f32 '
+                                     '(the reference\'s arithmetic)'
+                                     % ('fp16 overflow inside the trunk' if overflow else 'non-finite descriptors', dtype))
+        # bf16 / f32 share fp32's range: inf / NaN here come from the checkpoint or the input, not from the format
+        raise FloatingPointError('non-finite descriptors with compute dtype %s: the checkpoint or the input holds '
+                                 'inf / NaN values (this format has fp32\'s range)' % dtype)
     return feats
 
 
@@ -77,9 +81,19 @@ class StreamPool(object):
     interleaving changes (scripts/exp_stream_race.py: 0 of 7 680 forwards differ; that script is also how the one
     kernel whose emitted code depended on timing was found - csrc/dir_common.h ring_barrier)."""
 
+    _shared = {}      # (device, n) -> the process-wide streams of that pool size
+
     def __init__(self, n=None):
         n = int(os.environ.get('DIRTORCH_AMD_STREAMS', '4')) if n is None else n
-        self.streams = [torch.cuda.Stream() for _ in range(n)] if n > 1 and torch.cuda.is_available() else []
+        self.streams = []
+        if n > 1 and torch.cuda.is_available():
+            # ONE set of streams per device and pool size for the whole process: the engine keeps a workspace per stream
+            # (nets/rmac_resnet.py _workspace, 0.2 ... 1+ GB each), so a fresh set of streams per extraction call - torch
+            # hands out 32 distinct ones before it wraps - would leave up to 33 workspaces allocated over an evaluation
+            key = (torch.cuda.current_device(), n)
+            if key not in StreamPool._shared:
+                StreamPool._shared[key] = [torch.cuda.Stream() for _ in range(n)]
+            self.streams = StreamPool._shared[key]
         self.i = 0
 
     def run(self, fn, *inputs):
@@ -117,7 +131,8 @@ def extract_image_features(dataset, transforms, net, ret_imgs=False, same_size=F
         return _check_finite(_extract_bucketed(loader, len(dataset), net, batch_size, desc), net)
     feats, kept = [], []
     nbatches = (len(dataset) + bs - 1) // bs
-    pool_ = StreamPool(None if (bs == 1 and net.iscuda) else 1)
+    # (per-launch profiling records events of ONE stream in issue order: overlapping forwards would interleave them)
+    pool_ = StreamPool(None if (bs == 1 and net.iscuda and not getattr(net, '_profiling', False)) else 1)
     with torch.no_grad():
         for (imgs,) in tqdm.tqdm(loader, desc, total=nbatches):
             if flip:

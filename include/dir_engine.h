@@ -16,8 +16,12 @@
  *   - activations are NHWC, 16-bit (bf16 or fp16; DIR_FP16P: pairs of fp16 planes in the stem and layer1) or fp32
  *     (DIR_F32, the strict path), chosen at finalize; accumulation is always fp32.
  *   - the engine owns only its packed weights; the caller owns images, descriptors and workspace.
- *   - a handle is not re-entrant: one handle per device, one calling thread at a time
- *     (the reference calls net(x) from one thread, dirtorch/test_dir.py:67-81).
+ *   - one handle per device, ONE calling thread at a time (the reference calls net(x) from one thread,
+ *     dirtorch/test_dir.py:67-81).  That thread may keep several dir_forward calls in flight on DIFFERENT streams of the
+ *     device (the host mirror overlaps batch-1 forwards on four, dirtorch_amd/test_dir.py StreamPool): every per-forward
+ *     mutable state is host-side and each call takes its own caller-owned workspace - one workspace per stream.  Two
+ *     things are per handle, not per stream: the overflow word (join all streams before dir_engine_overflow) and the
+ *     profile records (enable profiling with forwards on a single stream only - events of several streams interleave).
  */
 #ifndef DIR_ENGINE_H
 #define DIR_ENGINE_H

@@ -1,9 +1,10 @@
+#!/bin/bash
 # SQ / cache counters per kernel for bench.py (diagnosis; separate --pmc passes, kernel-trace only)
 set -x
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=$PWD
 export DIRTORCH_AMD_TUNE_CACHE=$R/gpurun_out/tune_pmc.txt
 ARGS="--steps 2 --warmup 1 --cpu-seconds 0 --autotune"
 timeout 300 python bench.py $ARGS > /dev/null 2>&1   # writes the tuning cache

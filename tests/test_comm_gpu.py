@@ -40,3 +40,36 @@ def test_single_process_allgather_over_rccl():
         _lib.call('dir_comm_destroy', comm)
     with pytest.raises(_lib.DirError):
         _lib.call('dir_comm_init_all', ndev + 7, None, ctypes.byref(comm))     # more devices than the box has
+
+
+def _nccl_worker(rank, world, port, n, out):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from dirtorch_amd import distributed as dd
+    dd.init_from_env('nccl')
+    lo, hi = dd.shard_range(n)
+    g = torch.Generator().manual_seed(11)
+    full = torch.randn(n, 64, generator=g)
+    got = dd.allgather_rows(full[lo:hi].cuda(), n)           # RCCL all_gather_into_tensor of the padded blocks
+    out[rank] = bool(torch.equal(got.cpu(), full))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs at least two GPUs (the 1-GPU gpurun box skips it)')
+@pytest.mark.timeout(600)
+def test_torch_distributed_rccl_allgather_on_every_gpu():
+    """One process per GPU, world size = torch.cuda.device_count(), torch.distributed over RCCL: the exchange step of
+    dirtorch_amd.distributed (unequal shards: n % world != 0) equals the single-process concatenation bit for bit - what
+    tests/test_host_cpu.py pins over gloo, on the real collective the first multi-GPU box runs."""
+    import os
+    import torch.multiprocessing as mp
+    world = torch.cuda.device_count()
+    n = 1000 * world + world - 1
+    port = 29500 + (os.getpid() % 2000)
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_nccl_worker, args=(world, port, n, out), nprocs=world, join=True)
+        res = dict(out)
+    assert len(res) == world and all(res.values()), res

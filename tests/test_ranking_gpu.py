@@ -343,3 +343,54 @@ def test_split_similarity_ranks_like_the_exact_chain(tmp_path, monkeypatch):
     for a, b in zip(split, exact):
         for m in ('easy', 'medium', 'hard'):
             assert a[m] == pytest.approx(b[m], abs=1e-4), m
+
+
+@pytest.mark.parametrize('W', [2, 8])
+def test_sharded_scoring_with_unequal_shards(W):
+    """BASELINE configs[3] on 8 GPUs: 1 006 322 % 8 = 2, so the all-gathered database arrives as PADDED blocks with the
+    padding rows between the shards, and bench.py / a multi-GPU eval score it block by block
+    (dirtorch_amd.distributed.score_gathered).  Simulated on one GPU by slicing: N = 300 007 rows (N % W != 0, every
+    shard still long enough for the split-bf16 similarity kernel), W = 2 and 8.
+      * the two exchange layouts - descriptor blocks vs per-rank score blocks - give the same scores BIT FOR BIT (they
+        run the same similarity call on the same rows);
+      * against the un-sharded call the scores agree to fp32 summation order (sim_split rotates each row tile's
+        starting K slab by its tile index, so a row's sum order depends on where its tile sits in the call: same sum,
+        another association) and every AP to 1e-9."""
+    from dirtorch_amd import distributed as dd
+    from dirtorch_amd import ops, ranking
+    N, Q, D = 300007, 24, 2048
+    g = torch.Generator(device='cuda').manual_seed(7)
+    db = torch.empty(N, D, device='cuda')
+    for i in range(0, N, 65536):
+        n = min(65536, N - i)
+        db[i:i + n] = torch.nn.functional.normalize(torch.randn(n, D, generator=g, device='cuda'), dim=1)
+    qs = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device='cuda'), dim=1)
+    sizes, rows = dd.shard_sizes(N, W), dd.padded_rows(N, W)
+    assert rows * W != N and min(h - l for l, h in sizes) >= 32768
+    gathered = torch.zeros(W * rows, D, device='cuda')            # what all_gather_into_tensor of the padded blocks leaves
+    for r, (l, h) in enumerate(sizes):
+        gathered[r * rows:r * rows + (h - l)] = db[l:h]
+    s_desc = dd.score_gathered(qs, gathered, N, W, ops.similarity)
+    blocks = torch.stack([ops.similarity(qs, gathered[r * rows:(r + 1) * rows]) for r in range(W)])   # each rank's [Q, rows]
+    s_score = dd.merge_score_blocks(blocks, N, W)
+    assert s_desc.shape == (Q, N) and torch.equal(s_desc, s_score)
+    s_one = ops.similarity(qs, db)
+    assert float((s_desc - s_one).abs().max()) < 5e-7
+    ref = (qs[:4].double() @ db.double().T)
+    assert float((s_desc[:4].double() - ref).abs().max()) < 5e-7
+
+    class _DB(object):
+        relevants = None
+    r = np.random.RandomState(3)
+    d = _DB()
+    d.nimg, d.nquery, d.easy, d.hard, d.junk = N, Q, [], [], []
+    for q in range(Q):
+        idx = r.choice(N, 60, replace=False)
+        d.easy.append(sorted(idx[:20].tolist()))
+        d.hard.append(sorted(idx[20:40].tolist()))
+        d.junk.append(sorted(idx[40:].tolist()))
+    t = ranking.build_probe_tables(d)
+    a_sh, a_one = ranking.eval_aps_device(d, s_desc, t), ranking.eval_aps_device(d, s_one, t)
+    for x, y in zip(a_sh, a_one):
+        for k in x:
+            assert abs(x[k] - y[k]) < 1e-9, (k, x[k], y[k])
