@@ -77,7 +77,6 @@ hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stre
 bool conv_patch64_lc_admissible(const ConvArgs& a);
 hipError_t conv_patch64_lc_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_ring_admissible(const ConvArgs& a);
-bool conv1x1_ring_dual_admissible(const ConvArgs& a);   // the two-source form (ConvArgs::x2) of the same kernel
 hipError_t conv1x1_ring_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_wreg_admissible(const ConvArgs& a);
 hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream);

@@ -650,16 +650,9 @@ int conv_pick_dual_variant(const ConvArgs& a) {
     // 128 VGPRs with the second source's offsets and loses its occupancy)
     // (a two-source instantiation of the 3-slot 128x256 tile, two stages in flight, measured 0.39 / 0.29 / 0.22 ms
     // against 0.31 / 0.24 / 0.19 ms on the first blocks of layers 2 / 3 / 4 - gpurun_out/r3i - and was removed)
-    {
-        // the split loader / consumer ring (conv_ring.hip) has a two-source form too (bit-identical results); measured on
-        // the first blocks of layers 2 / 3 / 4 it runs 0.357 / 0.267 / 0.224 ms against 0.342 / 0.254 / 0.215 ms for the
-        // one-role 256x256 tile (gpurun_out/r3p): four consumer waves - one per SIMD - multiply slower than eight, and
-        // these GEMMs are not memory-bound enough for the overlap to pay.  DIRTORCH_AMD_DUAL_RING=force selects it
-        // wherever it is admissible (the tests do; read per call).
-        const char* mode = getenv("DIRTORCH_AMD_DUAL_RING");
-        const int r = find_variant("128x256_ring1x1");
-        if (r >= 0 && mode && mode[0] == 'f' && conv1x1_ring_dual_admissible(a)) return r;
-    }
+    // (a two-source form of the split loader / consumer ring, conv_ring.hip, was measured in round 3 - bit-identical,
+    // 0.357 / 0.267 / 0.224 ms against 0.342 / 0.254 / 0.215 ms for this one-role tile: four consumer waves multiply slower
+    // than eight and these GEMMs are not memory-bound enough for the overlap to pay - and retired in round 4)
     if (a.Cout % 256 != 0 || (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192) return -1;
     const int v = find_variant("256x256_w4x2");
     if (v < 0 || kVariants[v].launch_dual[0] == nullptr || a.Cout % kVariants[v].BN != 0) return -1;
@@ -747,14 +740,6 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv: bad dtype");
     if (a.x2) {   // two-source K: conv3 + downsample in one GEMM
         if (variant < 0) variant = conv_pick_dual_variant(a);
-        if (variant >= 0 && variant < kNumVariants && kVariants[variant].kind == 7) {   // conv_ring.hip's two-source form
-            if (!conv1x1_ring_dual_admissible(a) || ((uintptr_t)a.x2 & 15) || (long)a.B * a.H2 * a.W2 * a.Cin2 >= (1L << 30))
-                return fail(DIR_ERR_INVALID, "conv: no two-source form for this shape / variant");
-            hipError_t e = conv1x1_ring_launch(a, dtype, stream);
-            if (e != hipSuccess)
-                return fail(DIR_ERR_HIP, std::string("conv launch ") + kVariants[variant].name + "/dual: " + hipGetErrorString(e));
-            return DIR_OK;
-        }
         if (variant < 0 || variant >= kNumVariants || kVariants[variant].launch_dual[0] == nullptr ||
             a.Cout % kVariants[variant].BN != 0 || a.R != 1 || a.S != 1 || a.stride != 1 || a.res || a.ksplit > 1 ||
             a.Cin2 % 64 != 0 || a.Ktot != a.Cin + a.Cin2 || ((uintptr_t)a.x2 & 15) ||

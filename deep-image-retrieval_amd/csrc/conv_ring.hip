@@ -24,11 +24,6 @@
 // Form kept here: the split-role ring with direct stores (the simplest of the four, 80 us standalone, within 2 us of
 // conv_persist.hip inside the network; 9 us faster on the 512 -> 256 conv1 of layer3's first block).  It is in the
 // autotuner's pool and selectable by name; the built-in heuristic keeps conv_persist.hip.
-// It also has a two-source form (template DUAL: conv3 + the strided 1x1 downsample of a stage's first block as one GEMM,
-// the pixel loader switching tensors at the source boundary of every tile): bit-identical to conv_igemm.hip's two-source
-// tile and 4-5 % slower than it on the first blocks of layers 2-4 (0.357 / 0.267 / 0.224 vs 0.342 / 0.254 / 0.215 ms) - four
-// consumer waves multiply slower than eight, and those GEMMs are not memory-bound enough for the overlap to pay.  Opt-in
-// (DIRTORCH_AMD_DUAL_RING=force), tested, not a default.
 //   * tile 128 pixels x 256 channels, K-step 64: a stage is 16 KB of pixels + 32 KB of weights, THREE slots
 //     (144 KB), two stages always in flight; pixels are read from HBM exactly once, the weight panel is re-streamed
 //     from L2 once per 128 pixels;
@@ -64,10 +59,7 @@ __device__ __forceinline__ uint32_t fast_div_r(uint32_t n, uint32_t mul, uint32_
 }
 
 // LDS map: [0, 144K) ring, [144K, 152K) bias (Cout <= 2048).
-// DUAL: the K dimension comes from TWO tensors (conv3 + the 1x1 strided downsample of a stage's first block as one GEMM,
-// conv_igemm.hip's two-source form): K-steps [0, Cin / 64) from x (flat), the rest from x2 through the strided pixel map
-// (b, oh, ow) -> (b, oh * stride2, ow * stride2); the weights arrive concatenated along K.  Only the pixel loader differs.
-template <class DT, bool DUAL>
+template <class DT>
 __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
     constexpr int BM = 128, BN = 256;
     constexpr int TM = 2, TN = 4;              // consumer tile 64 pixels x 128 channels (2 x 2 consumer waves)
@@ -123,12 +115,9 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
         const uint32_t src_bytes = is_x ? a.x_bytes : a.w_bytes;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src_base, 0, src_bytes, 0x00020000);
         const int dst0 = is_x ? 0 : XS + (lw - 1) * NL * 1024;
-        const __amdgpu_buffer_rsrc_t rsrc2 =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : a.x_bytes, 0x00020000);
-        const int T1 = DUAL ? a.Cin / 64 : T;     // K-steps served by the first source
-        uint32_t voff[NL];   // (two-source form: the pixel loader rewrites these at the source boundary of every tile)
+        uint32_t voff[NL];
         // (always_inline: left as a call, the lambda takes the by-value argument struct by reference and parks it in scratch)
-        auto tile_offsets = [&](int tile, bool second) __attribute__((always_inline)) {
+        auto tile_offsets = [&](int tile) __attribute__((always_inline)) {
             const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
             if (is_x) {
 #pragma unroll
@@ -137,17 +126,15 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
                     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
                     const int m = tile_m * BM + row;
                     uint32_t off;
-                    if (a.flat && !(DUAL && second)) {
+                    if (a.flat) {
                         off = (uint32_t)((m * a.Cin + chunk * 8) * 2);
-                    } else {  // strided 1x1 / the second source: output pixel (b, oh, ow) -> input pixel (b, oh * s, ow * s)
+                    } else {  // strided 1x1: output pixel (b, oh, ow) -> input pixel (b, oh * s, ow * s)
                         const uint32_t mm = m < a.M ? (uint32_t)m : 0u;
                         const uint32_t b = fast_div_r(mm, a.div_ohw_mul, a.div_ohw_shr);
                         const uint32_t rem = mm - b * (uint32_t)(a.OH * a.OW);
                         const uint32_t oh = fast_div_r(rem, a.div_ow_mul, a.div_ow_shr);
                         const uint32_t ow = rem - oh * (uint32_t)a.OW;
-                        const uint32_t sh = DUAL && second ? (uint32_t)a.H2 : (uint32_t)a.H, sw = DUAL && second ? (uint32_t)a.W2 : (uint32_t)a.W;
-                        const uint32_t st = DUAL && second ? (uint32_t)a.stride2 : (uint32_t)a.stride;
-                        const uint32_t sc = DUAL && second ? (uint32_t)a.Cin2 : (uint32_t)a.Cin;
+                        const uint32_t sh = (uint32_t)a.H, sw = (uint32_t)a.W, st = (uint32_t)a.stride, sc = (uint32_t)a.Cin;
                         off = (uint32_t)((((b * sh + oh * st) * sw + ow * st) * sc + chunk * 8) * 2);
                     }
                     voff[k] = m < a.M ? off : kOOBr;
@@ -162,24 +149,17 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
             }
         };
         int is_tile = first, is_t = 0, is_slot = 0;
-        tile_offsets(first, false);
+        tile_offsets(first);
         auto issue_next = [&]() __attribute__((always_inline)) {
             char* dst = smem + is_slot * STAGE + dst0;
-            if (DUAL && is_x && is_t >= T1) {
 #pragma unroll
-                for (int k = 0; k < NL; ++k) dma16r(rsrc2, dst + k * 1024, voff[k], (is_t - T1) * 128);
-            } else {
-#pragma unroll
-                for (int k = 0; k < NL; ++k)
-                    if (!(DIR_RING_ABL & (is_x ? 1 : 2))) dma16r(rsrc, dst + k * 1024, voff[k], is_t * 128);
-            }
+            for (int k = 0; k < NL; ++k)
+                if (!(DIR_RING_ABL & (is_x ? 1 : 2))) dma16r(rsrc, dst + k * 1024, voff[k], is_t * 128);
             is_slot = is_slot + 1 == NSLOT ? 0 : is_slot + 1;
             if (++is_t == T) {
                 is_t = 0;
                 is_tile += (int)gridDim.x;
-                if (is_tile < ntiles) tile_offsets(is_tile, false);
-            } else if (DUAL && is_x && is_t == T1) {
-                tile_offsets(is_tile, true);   // from here on the K-steps of this tile come from the second source
+                if (is_tile < ntiles) tile_offsets(is_tile);
             }
         };
         issue_next();
@@ -292,22 +272,16 @@ __global__ void __launch_bounds__(512) conv1x1_ring_kernel(const ConvArgs a) {
     ovf.flush(a.ovf);
 }
 
-bool conv1x1_ring_dual_admissible(const ConvArgs& a) {
-    return a.x2 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
-           a.Cout % 256 == 0 && a.Cout <= 2048 && a.Cin % 64 == 0 && a.Cin2 % 64 == 0 && a.Ktot == a.Cin + a.Cin2 &&
-           a.res == nullptr;
-}
-
 bool conv1x1_ring_admissible(const ConvArgs& a) {
     return a.R == 1 && a.S == 1 && a.pad == 0 && a.Cout % 256 == 0 && a.Cout <= 2048 && a.Cin % 64 == 0 &&
-           a.Cin >= 128 && a.res == nullptr;
+           a.Cin >= 128 && a.res == nullptr && a.x2 == nullptr;
 }
 
-template <class DT, bool DUAL>
+template <class DT>
 static hipError_t launch_ring(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 3 * (128 + 256) * 128 + 2048 * 4;   // ring + bias
     static_assert(LDS <= 160 * 1024, "LDS map");
-    auto kern = conv1x1_ring_kernel<DT, DUAL>;
+    auto kern = conv1x1_ring_kernel<DT>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -317,7 +291,6 @@ static hipError_t launch_ring(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
-    if (DUAL) b.x2_bytes = (uint32_t)((size_t)a.B * a.H2 * a.W2 * a.Cin2 * 2);
     static const bool no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting (read once)
     b.no_xcd_map = no_xcd_map;
     auto fd = [](uint32_t d, uint32_t& mul, uint32_t& shr) {   // exact n / d for n < 2^31 (as in conv_igemm.hip)
@@ -337,8 +310,7 @@ static hipError_t launch_ring(const ConvArgs& a, hipStream_t stream) {
 }
 
 hipError_t conv1x1_ring_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
-    if (a.x2) return dtype == DIR_BF16 ? launch_ring<BF16, true>(a, stream) : launch_ring<FP16, true>(a, stream);
-    return dtype == DIR_BF16 ? launch_ring<BF16, false>(a, stream) : launch_ring<FP16, false>(a, stream);
+    return dtype == DIR_BF16 ? launch_ring<BF16>(a, stream) : launch_ring<FP16>(a, stream);
 }
 
 }  // namespace dir

@@ -71,9 +71,9 @@ def short(name):
     m = re.search(r'conv_patch64_lc_kernel<dir::(\w+)>', name)
     if m:
         return 'conv_igemm<256x64_patchlc3x3>[%s]' % m.group(1).lower()
-    m = re.search(r'conv1x1_ring_kernel<dir::(\w+)(?:, (\w+))?>', name)
+    m = re.search(r'conv1x1_ring_kernel<dir::(\w+)>', name)
     if m:
-        return 'conv_igemm<128x256_ring1x1%s>[%s]' % ('/dual' if m.group(2) == 'true' else '', m.group(1).lower())
+        return 'conv_igemm<128x256_ring1x1>[%s]' % m.group(1).lower()
     m = re.search(r'conv1x1_persist_kernel<dir::(\w+)(?:, (\w+), (\w+))?>', name)
     if m:
         return 'conv_igemm<256x256_persist1x1%s>[%s]' % ('_x3' if m.group(2) == 'true' else '', m.group(1).lower())
