@@ -28,6 +28,7 @@ Two more workloads keep the same flags and JSON contract (the default above is B
   --workload multiscale    configs[4]: three scales of resident uint8 1200^2 images, fp16, device-side resize
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -356,6 +357,8 @@ def bench_distractors(args, world, rank, dist):
     for _ in range(max(Wm, 1)):
         aps = step(False)
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()          # (no cycle collection inside the timed region: see the extract workload)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -366,6 +369,7 @@ def bench_distractors(args, world, rank, dist):
     if dist is not None:
         dist.barrier()
     el = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([el], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -446,6 +450,8 @@ def bench_multiscale(args, world, rank, dist):
     for _ in range(max(Wm, 2)):
         step()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()          # (no cycle collection inside the timed region: see the extract workload)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -463,6 +469,7 @@ def bench_multiscale(args, world, rank, dist):
         t = torch.tensor([el], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    gc.enable()
     if rank != 0:
         return None
     # ResNet-101 trunk: 448.76 GFLOP at 1200^2, quadratic in the side
@@ -567,13 +574,25 @@ def main():
     torch.cuda.synchronize()
 
     net.set_profiling(256 * (K + 1))    # event pairs pre-created: nothing is allocated while timing
+    # The host is ~40x ahead of the GPU here (0.3 ms to enqueue a 13 ms step) - unless the interpreter's cycle collector
+    # picks the first timed step for a full collection of the process's heap (torch + the checkpoint: 35-55 ms measured,
+    # gpurun_out/r4f-r4g: the GPU then idles with an empty queue and every step of a 12-step run reads 3 ms slower).
+    # Collect now, keep the collector out of the timed region.
+    gc.collect()
+    gc.disable()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    _trace = [] if os.environ.get('DIRTORCH_AMD_BENCH_TRACE') else None   # (debug: host enqueue time of every step)
     for k in range(K):
         net.pause_profiling(k % args.profile_every != 0)   # event records only on sampled steps
+        _a = time.perf_counter()
         shard[k * B:(k + 1) * B] = net(x)
+        if _trace is not None:
+            _trace.append(round((time.perf_counter() - _a) * 1e3, 2))
+    if _trace is not None:
+        print('enqueue ms per step:', _trace, file=sys.stderr)
     if dist is not None:
         allb = torch.empty(world * K * B, D, device='cuda')
         dist.all_gather_into_tensor(allb, shard)                  # one exchange step (RCCL)
@@ -585,6 +604,7 @@ def main():
         t = torch.tensor([el], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    gc.enable()
     prof = net.get_profile()
     net.set_profiling(False)
 

@@ -2,7 +2,10 @@
 """Batch-1 extraction (the reference's real workload, dirtorch/test_dir.py:52-55: one image per forward at its native
 size) on one MI355X: images/sec of ResNet-101 at 1024x1024 and 1024x768 with the forwards issued round-robin on
 1 ... 6 HIP streams (dirtorch_amd.test_dir.StreamPool - what the extraction loops use).  Prints one JSON line.
-    python scripts/bench_batch1.py [--dtype fp16] [--n 96]"""
+(Round 4 also measured hipGraph replays of the captured forward here - 702 vs 694 img/s on one stream, 985 vs 979 on four,
+profiles/r04_batch1_graph.json: the ~110 launches of a batch-1 forward are bound by the kernels' own 8-13 us on the
+device, not by the host's launch cost - and dropped the capture path again.)
+    python scripts/bench_batch1.py [--dtype fp16p] [--n 96]"""
 import argparse
 import json
 import os
@@ -20,7 +23,7 @@ from dirtorch_amd.test_dir import StreamPool  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--dtype', default='fp16')
+    ap.add_argument('--dtype', default='fp16p')
     ap.add_argument('--arch', default='resnet101')
     ap.add_argument('--n', type=int, default=96)
     args = ap.parse_args()

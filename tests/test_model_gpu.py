@@ -303,3 +303,4 @@ def test_fused_seams_inside_the_network(monkeypatch):
     monkeypatch.setenv('DIRTORCH_AMD_C3C1', '0')
     d_plain = make_net('resnet50', {}, sd, 'bf16')(x[:2, :256, :256].contiguous())
     assert np.all(1 - O.cosine(d_forced.cpu().numpy(), d_plain.cpu().numpy()) < 1e-5)
+
