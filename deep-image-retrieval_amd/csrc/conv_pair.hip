@@ -191,6 +191,27 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
         }
     };
 
+    // ---- residual tile (both planes) fetched up front: its HBM latency hides under the K loop (conv_igemm.hip's
+    //      PRE_RES).  Read in the epilogue it cost eight exposed round trips per wave and tile: conv3 of the paired
+    //      layer1 ran at 0.81 ms for 2.7 GB, 3.3 TB/s. -----------------------------------------------------------------
+    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
+    const int ecol = (lane % LPR) * 8;
+    const int erow = lane / LPR;
+    const int n_glob = tile_n * BN + wn * TN * 32 + ecol;
+    const int m_epi = tile_m * BM + wm * TM * 32;
+    u32x4_t rres_h[TM][NPASS], rres_l[TM][NPASS];
+    if (a.res) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m = m_epi + j * 32 + pass * RPP + erow;
+                const size_t o = (size_t)(m < a.M ? m : 0) * a.Cout + n_glob;   // clamped rows are never stored
+                rres_h[j][pass] = gload16(a.res + o);
+                if (a.res_lo) rres_l[j][pass] = gload16(a.res_lo + o);
+            }
+    }
+
     // ---- K loop: channel slice outermost, filter taps innermost (conv_igemm.hip's order); two slots -----------------
     const int cpb = a.Cin / BK;
     const int T = a.T;
@@ -225,11 +246,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
     Ovf<DT> ovf;
 
     // ---- epilogue: acc -> LDS (fp32, pixel-major) -> + residual pair -> ReLU -> split into (hi, lo) -> 16-byte stores
-    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
-    const int ecol = (lane % LPR) * 8;
-    const int erow = lane / LPR;
-    const int n_glob = tile_n * BN + wn * TN * 32 + ecol;
-    const int m_epi = tile_m * BM + wm * TM * 32;
     char* ebase = smem + wave * (32 * EROW);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -253,7 +269,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
                 float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
                 const size_t o = (size_t)m * a.Cout + n_glob;
                 if (a.res) {
-                    const u32x4_t rh = gload16(a.res + o);
+                    const u32x4_t rh = rres_h[j][pass];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float lo, hi;
@@ -262,7 +278,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
                         v[2 * e + 1] += hi;
                     }
                     if (a.res_lo) {
-                        const u32x4_t rl = gload16(a.res_lo + o);
+                        const u32x4_t rl = rres_l[j][pass];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float lo, hi;
@@ -294,6 +310,198 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_pair_kernel(const ConvArg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     ovf.flush(a.ovf);
+}
+
+// ---- 3x3 stride 1, 64 -> 64 channels, from an LDS-resident patch PAIR (layer1's conv2) --------------------------------------
+// The implicit-GEMM form above re-fetches the activation tile once per filter tap and plane: 18 x the input through the
+// CU's memory pipe (0.60 ms per launch at batch 32, 1.8 TB/s).  Here (conv_patch.hip's idea) a workgroup loads the
+// (4 + 2) x (32 + 2) pixel patch of its 4 x 32 output tile ONCE per plane (hi, lo: 2 x 28 KB) and the nine taps read it at
+// shifted pixel offsets; only the weights stream: one [64][64] slice per (tap, plane) step through a 3-slot ring of 8 KB.
+// A hi step multiplies w_hi by both patch planes, the lo step that follows it w_lo by the hi plane: the same three
+// products per term.  80 KB of LDS and 4 waves: two workgroups per CU, one's patch load under the other's MFMAs.
+__global__ void __launch_bounds__(256, 2) conv_pair_patch64_kernel(const ConvArgs a) {
+    typedef FP16 DT;
+    typedef DT::frag_t frag_t;
+    constexpr int TH = 4, TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;   // 204 patch pixels
+    constexpr int C = 64, NTH = 256;
+    constexpr int NPL = (PP * 8 + NTH - 1) / NTH;       // 7 DMA instructions per lane per plane
+    constexpr int PLANE_BYTES = NPL * NTH * 16;         // 28672
+    constexpr int WSTAGE = C * 128, NBW = C * 8 / NTH, NSTW = 3;
+    constexpr int WOFF = 2 * PLANE_BYTES;
+    constexpr int TN = 2;
+    constexpr int EROW = TN * 128 + 16;
+    constexpr int NS = 18;                              // (tap, plane) steps
+    static_assert(WOFF + NSTW * WSTAGE <= 80 * 1024 && 4 * 32 * EROW <= WOFF, "two workgroups per CU; staging aliases the patch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = output row of the tile
+    const int lrow = lane & 31, lhi = lane >> 5;
+
+    const int tiles_x = (a.OW + TW - 1) / TW;
+    const int tiles_y = (a.OH + TH - 1) / TH;
+    int wg = blockIdx.x;
+    const int tx = wg % tiles_x;
+    wg /= tiles_x;
+    const int ty = wg % tiles_y;
+    const int b = wg / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_xh = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_xl = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_lo, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_lo, 0, a.w_bytes, 0x00020000);
+
+    // ---- patch pair: PP pixels x 128 B per plane, chunks XOR-swizzled with (p >> 1) & 7, loaded once ----------------------
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int P = i * NTH + tid;
+        const int p = P >> 3, slot = P & 7;
+        const int py = p / PW, px = p - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = p < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const uint32_t v = ok ? (uint32_t)((((b * a.H + iy) * a.W + ix) * C + ((slot ^ ((p >> 1) & 7)) << 3)) * 2) : kOOBp;
+        dma16p(rsrc_xh, smem + (i * NTH + wave * 64) * 16, v, 0);
+        dma16p(rsrc_xl, smem + PLANE_BYTES + (i * NTH + wave * 64) * 16, v, 0);
+    }
+    // ---- weights: step sigma = (tap, plane) -> the [64][64] slice of that tap from w_hi / w_lo -----------------------------
+    const int srcchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    uint32_t wvoff[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) wvoff[i] = (uint32_t)(((i * (NTH / 8) + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
+    auto issue_w = [&](int sigma, int slot) {
+        const int tap = sigma >> 1;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            char* dst = smem + WOFF + slot * WSTAGE + (i * NTH + wave * 64) * 16;
+            if (sigma & 1) {
+                dma16p(rsrc_wl, dst, wvoff[i], tap * 128);
+            } else {
+                dma16p(rsrc_wh, dst, wvoff[i], tap * 128);
+            }
+        }
+    };
+
+    f32x16_t acc[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + i * 32 + 8 * g + 4 * lhi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][4 * g + e] = b4[e];
+        }
+    const int wswz = (lane >> 1) & 7;
+    int woffk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) woffk[ks] = lrow * 128 + (((2 * ks + lhi) ^ wswz) << 4);
+
+    issue_w(0, 0);
+    issue_w(1, 1);
+    int slot_c = 0;
+    for (int sigma = 0; sigma < NS; ++sigma) {
+        if (sigma + 1 < NS) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NBW) : "memory");   // the newest stage may stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ring_barrier();   // the patch pair (issued first) and weight stage sigma have landed; everyone left stage sigma - 1
+        if (sigma + 2 < NS) {
+            int slot_n = slot_c + 2;
+            if (slot_n >= NSTW) slot_n -= NSTW;
+            issue_w(sigma + 2, slot_n);
+        }
+        const int tap = sigma >> 1, r = tap / 3, sx = tap - 3 * r;
+        const int p = (wave + r) * PW + sx + lrow;          // patch pixel this lane reads
+        const int swz = (p >> 1) & 7;
+        const char* rowh = smem + p * 128;
+        const char* wst = smem + WOFF + slot_c * WSTAGE;
+        if ((sigma & 1) == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const frag_t xh = *(const frag_t*)(rowh + (((2 * ks + lhi) ^ swz) << 4));
+                const frag_t xl = *(const frag_t*)(rowh + PLANE_BYTES + (((2 * ks + lhi) ^ swz) << 4));
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const frag_t wf = *(const frag_t*)(wst + i * 4096 + woffk[ks]);
+                    acc[i] = DT::mfma32(wf, xh, acc[i]);
+                    acc[i] = DT::mfma32(wf, xl, acc[i]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const frag_t xh = *(const frag_t*)(rowh + (((2 * ks + lhi) ^ swz) << 4));
+#pragma unroll
+                for (int i = 0; i < TN; ++i) acc[i] = DT::mfma32(*(const frag_t*)(wst + i * 4096 + woffk[ks]), xh, acc[i]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (++slot_c == NSTW) slot_c = 0;
+    }
+    __syncthreads();   // the patch becomes epilogue staging
+    Ovf<DT> ovf;
+
+    char* ebase = smem + wave * (32 * EROW);
+    constexpr int LPR = TN * 4, RPP = 64 / LPR, NPASS = 32 / RPP;
+    const int ecol = (lane % LPR) * 8, erow = lane / LPR;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4_t v = {acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+            *(f32x4_t*)(ebase + lrow * EROW + (i * 32 + 8 * g + 4 * lhi) * 4) = v;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int oy = oy0 + wave;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int mrow = pass * RPP + erow;
+        const f32x4_t f0 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4);
+        const f32x4_t f1 = *(const f32x4_t*)(ebase + mrow * EROW + ecol * 4 + 16);
+        const int ox = ox0 + mrow;
+        if (oy < a.OH && ox < a.OW) {
+            float v[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x4_t oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h, l;
+                split2(v[2 * e], v[2 * e + 1], h, l);
+                oh[e] = h;
+                ol[e] = l;
+            }
+            const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * C + ecol;
+            gstore16(a.y + o, oh);
+            if (a.y_lo) gstore16(a.y_lo + o, ol);
+            ovf.see(oh);
+        }
+    }
+    ovf.flush(a.ovf);
+}
+
+static bool pair_patch64_admissible(const ConvArgs& a) {
+    return a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.H == a.OH && a.W == a.OW && a.Cin == 64 &&
+           a.Cout == 64 && a.x_lo && !a.res && !a.x2;
+}
+
+static hipError_t launch_pair_patch64(const ConvArgs& a, hipStream_t stream) {
+    constexpr int LDS = 2 * 7 * 256 * 16 + 3 * 64 * 128;   // patch pair + three weight slots = 80 KiB
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t e = ensure_dynamic_lds((const void*)conv_pair_patch64_kernel, LDS, attr_done); e != hipSuccess) return e;
+    ConvArgs b = a;
+    b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
+    b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
+    const long blocks = (long)a.B * ((a.OH + 3) / 4) * ((a.OW + 31) / 32);
+    hipLaunchKernelGGL(conv_pair_patch64_kernel, dim3((unsigned)blocks), dim3(256), LDS, stream, b);
+    return hipGetLastError();
 }
 
 static void fastdiv_init_p(uint32_t d, uint32_t& mul, uint32_t& shr) {
@@ -336,10 +544,18 @@ static hipError_t launch_pair(const ConvArgs& a, hipStream_t stream) {
 }
 
 // 128 pixels x 128 channels for the wide outputs (the pixel tile is fetched once per 128 channels), x 64 otherwise
+// (64-channel tiles for the wide outputs too - three workgroups per CU instead of two - measured 4-6 % slower on every
+// 1x1 of the paired layer1, gpurun_out/r4h)
 static bool pair_wide(const ConvArgs& a) { return a.Cout % 128 == 0; }
+
+// DIRTORCH_AMD_NO_PAIR_PATCH=1: layer1's 3x3 back on the implicit-GEMM form (A/B and bisecting; read per call)
+static bool use_pair_patch64(const ConvArgs& a) {
+    return pair_patch64_admissible(a) && getenv("DIRTORCH_AMD_NO_PAIR_PATCH") == nullptr;
+}
 
 const char* conv_pair_variant_name(const ConvArgs& a) {
     if (a.x2) return "128x128_xw/dual";
+    if (use_pair_patch64(a)) return "128x64_patch3x3_xw";
     return pair_wide(a) ? (a.x_lo ? "128x128_xw" : "128x128_w") : (a.x_lo ? "128x64_xw" : "128x64_w");
 }
 
@@ -356,7 +572,9 @@ int conv_pair_launch(const ConvArgs& a, hipStream_t stream) {
     for (const void* p : ptrs)
         if ((uintptr_t)p & 15) return fail(DIR_ERR_INVALID, "conv_pair: tensors must be 16-byte aligned");
     hipError_t e;
-    if (a.x2) {   // two-source form: conv3 + the stride-1 downsample of the paired head's first block
+    if (use_pair_patch64(a)) {
+        e = launch_pair_patch64(a, stream);
+    } else if (a.x2) {   // two-source form: conv3 + the stride-1 downsample of the paired head's first block
         const bool flat = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW;
         if (!flat || a.Cin2 != a.Cin || a.Ktot != 2 * a.Cin || !a.x_lo || !a.x2_lo || a.res || a.Cout % 128 != 0 ||
             ((uintptr_t)a.x2 & 15) || ((uintptr_t)a.x2_lo & 15))

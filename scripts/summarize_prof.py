@@ -59,6 +59,8 @@ def short(name):
     if m:   # the paired-fp16 head of DIR_FP16P (csrc/conv_pair.hip): <BM, BN, WGM, WGN, XP[, DUAL]>
         return 'conv_pair<%sx%s_%sw%s>' % (m.group(1), m.group(2), 'x' if m.group(5) == 'true' else '',
                                            '/dual' if m.group(6) == 'true' else '')
+    if 'conv_pair_patch64_kernel' in name:   # layer1's 3x3 on a patch pair (csrc/conv_pair.hip)
+        return 'conv_pair<128x64_patch3x3_xw>'
     m = re.search(r'conv_f32_kernel<(\d+)>', name)
     if m:   # the strict fp32 path (csrc/conv_f32.hip)
         return 'conv_f32<128x%s>' % m.group(1)

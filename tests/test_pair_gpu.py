@@ -43,7 +43,9 @@ def join(pair):
 # (DIRTORCH_AMD_PAIR_STAGES > 1) would add
 GEOMS = [
     (2, 16, 24, 64, 64, 1, 1, 0, False, True),      # layer1.0.conv1
-    (1, 17, 13, 64, 64, 3, 1, 1, False, True),      # conv2, M = 221: ragged 128-pixel tiles
+    (1, 17, 13, 64, 64, 3, 1, 1, False, True),      # conv2 (the patch-pair kernel): one ragged column of 4 x 32 tiles
+    (2, 41, 70, 64, 64, 3, 1, 1, False, True),      # ... 11 x 3 tiles per image, ragged both ways
+    (1, 8, 64, 64, 64, 3, 1, 1, False, False),      # ... exact tiles, no ReLU
     (2, 16, 16, 64, 256, 1, 1, 0, True, True),      # conv3 + residual pair + ReLU (128-channel tiles)
     (2, 16, 16, 64, 256, 1, 1, 0, False, False),    # the stride-1 downsample (no ReLU)
     (2, 12, 20, 256, 64, 1, 1, 0, False, True),     # conv1 of the later blocks, K = 256
@@ -94,6 +96,15 @@ def test_pair_conv_vs_torch_fp32(geom):
     ref1 = reference(xp[0].cpu().permute(0, 3, 1, 2).double(), rp[0].float() if with_res else None)
     y1 = ops.conv_bn_act_pair(xp[0], wp, bias.cuda(), rp[0] if with_res else None, stride=stride, pad=pad, relu=relu)
     assert float((join(y1).cpu().double() - ref1).abs().max()) < 4e-6 * scale
+    if k == 3 and Cin == 64 and Cout == 64 and not with_res:
+        # the patch-pair kernel (default for this shape) against the implicit-GEMM form of the same convolution
+        import os
+        os.environ['DIRTORCH_AMD_NO_PAIR_PATCH'] = '1'
+        try:
+            yi = ops.conv_bn_act_pair(xp, wp, bias.cuda(), rp, stride=stride, pad=pad, relu=relu)
+        finally:
+            del os.environ['DIRTORCH_AMD_NO_PAIR_PATCH']
+        assert float((join(yi) - join(y)).abs().max()) < 4e-6 * scale
     # zero padding / ragged-tile masks: an all-zero input gives relu(bias (+ res)) to pair precision
     z = ops.conv_bn_act_pair((torch.zeros_like(xp[0]), torch.zeros_like(xp[1])), wp, bias.cuda(), rp, stride=stride,
                              pad=pad, relu=relu)
