@@ -93,8 +93,8 @@ def main():
                     continue
                 d = head(features(sd, arch, x, dt, set(R)))
                 print('%-5s %-78s %.2e' % (dname, label, float((1 - (d * d0).sum(1)).max())))
-        d = O.rmac_forward(sd, arch, x, quant='fp16p')
-        dref = O.rmac_forward(sd, arch, x)
+        d = O.rmac_forward(sd, arch, x, quant='fp16p').reshape(B, -1)      # (B == 1 comes back squeezed)
+        dref = O.rmac_forward(sd, arch, x).reshape(B, -1)
         print("oracle quant='fp16p' (pairs ~22 bits, not exact; full head incl. FC)                      %.2e"
               % float((1 - (d * dref).sum(1)).max()))
 
