@@ -495,7 +495,7 @@ def bench_multiscale(args, world, rank, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--arch', default='resnet101')
@@ -520,7 +520,7 @@ def main():
     ap.add_argument('--exchange', default='descriptors', choices=['descriptors', 'scores'],
                     help="distractors: what crosses xGMI - the [N/W, 2048] descriptor blocks (north_star) or, the "
                          "cheaper layout, each rank's [Q, N/W] score block")
-    ap.add_argument('--profile-every', type=int, default=4,
+    ap.add_argument('--profile-every', type=int, default=10,
                     help='record per-launch HIP events on every n-th timed step (1 = all steps)')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer profile to stderr')
     ap.add_argument('--dump-launches', default='',
@@ -573,7 +573,7 @@ def main():
         net(x)
     torch.cuda.synchronize()
 
-    net.set_profiling(256 * (K + 1))    # event pairs pre-created: nothing is allocated while timing
+    net.set_profiling(256 * (K // max(args.profile_every, 1) + 2))    # event pairs pre-created: nothing is allocated while timing
     # The host is ~40x ahead of the GPU here (0.3 ms to enqueue a 13 ms step) - unless the interpreter's cycle collector
     # picks the first timed step for a full collection of the process's heap (torch + the checkpoint: 35-55 ms measured,
     # gpurun_out/r4f-r4g: the GPU then idles with an empty queue and every step of a 12-step run reads 3 ms slower).

@@ -401,7 +401,21 @@ __global__ void __launch_bounds__(256, 2) conv_pair_patch64_kernel(const ConvArg
     issue_w(0, 0);
     issue_w(1, 1);
     int slot_c = 0;
-    for (int sigma = 0; sigma < NS; ++sigma) {
+    // One iteration per tap = a hi step and a lo step (a hand-off barrier each).  The patch fragments of a tap (xh, xl: the
+    // patch is resident, they do not depend on the weight ring) are read ONCE for both steps, and those of the NEXT tap are
+    // requested before the lo step's MFMAs so that their LDS latency hides under those.
+    auto patch_frags = [&](int tap, frag_t* xh, frag_t* xl) {
+        const int r = tap / 3, sx = tap - 3 * r;
+        const int p = (wave + r) * PW + sx + lrow;          // patch pixel this lane reads
+        const int swz = (p >> 1) & 7;
+        const char* rowh = smem + p * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            xh[ks] = *(const frag_t*)(rowh + (((2 * ks + lhi) ^ swz) << 4));
+            xl[ks] = *(const frag_t*)(rowh + PLANE_BYTES + (((2 * ks + lhi) ^ swz) << 4));
+        }
+    };
+    auto hand_off = [&](int sigma) {
         if (sigma + 1 < NS) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NBW) : "memory");   // the newest stage may stay in flight
         } else {
@@ -413,35 +427,48 @@ __global__ void __launch_bounds__(256, 2) conv_pair_patch64_kernel(const ConvArg
             if (slot_n >= NSTW) slot_n -= NSTW;
             issue_w(sigma + 2, slot_n);
         }
-        const int tap = sigma >> 1, r = tap / 3, sx = tap - 3 * r;
-        const int p = (wave + r) * PW + sx + lrow;          // patch pixel this lane reads
-        const int swz = (p >> 1) & 7;
-        const char* rowh = smem + p * 128;
-        const char* wst = smem + WOFF + slot_c * WSTAGE;
-        if ((sigma & 1) == 0) {
+    };
+    frag_t xh[2][4], xl[2][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const frag_t xh = *(const frag_t*)(rowh + (((2 * ks + lhi) ^ swz) << 4));
-                const frag_t xl = *(const frag_t*)(rowh + PLANE_BYTES + (((2 * ks + lhi) ^ swz) << 4));
+    for (int tap = 0; tap < 9; ++tap) {
+        const int cur = tap & 1;
+        // ---- hi step: w_hi . (x_hi + x_lo) ---------------------------------------------------------------------------------
+        hand_off(2 * tap);
+        if (tap == 0) patch_frags(0, xh[0], xl[0]);          // (the patch has only just landed)
+        {
+            const char* wst = smem + WOFF + slot_c * WSTAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     const frag_t wf = *(const frag_t*)(wst + i * 4096 + woffk[ks]);
-                    acc[i] = DT::mfma32(wf, xh, acc[i]);
-                    acc[i] = DT::mfma32(wf, xl, acc[i]);
+                    acc[i] = DT::mfma32(wf, xh[cur][ks], acc[i]);
+                    acc[i] = DT::mfma32(wf, xl[cur][ks], acc[i]);
                 }
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const frag_t xh = *(const frag_t*)(rowh + (((2 * ks + lhi) ^ swz) << 4));
-#pragma unroll
-                for (int i = 0; i < TN; ++i) acc[i] = DT::mfma32(*(const frag_t*)(wst + i * 4096 + woffk[ks]), xh, acc[i]);
-            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's LDS reads retired before the next barrier
+        if (++slot_c == NSTW) slot_c = 0;
+        // ---- lo step: w_lo . x_hi ------------------------------------------------------------------------------------------------
+        hand_off(2 * tap + 1);
+        {
+            const char* wst = smem + WOFF + slot_c * WSTAGE;
+            frag_t wl[4][TN];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wl[ks][i] = *(const frag_t*)(wst + i * 4096 + woffk[ks]);
+            if (tap + 1 < 9) patch_frags(tap + 1, xh[cur ^ 1], xl[cur ^ 1]);   // next tap's pixels: 8 reads, newest in the queue
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i) acc[i] = DT::mfma32(wl[ks][i], xh[cur][ks], acc[i]);
+        }
+        // every LDS read retired before the next barrier (the next tap's patch reads had the eight MFMAs above to land; a
+        // counted wait that leaves them in flight would depend on the order hipcc emits the reads in)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (++slot_c == NSTW) slot_c = 0;
     }
-    __syncthreads();   // the patch becomes epilogue staging
+    ring_barrier();   // (every LDS read has retired, every DMA has landed: see the last step) the patch becomes epilogue staging
     Ovf<DT> ovf;
 
     char* ebase = smem + wave * (32 * EROW);
