@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py - images/sec of descriptor extraction (ResNet101-GeM, 1024x1024) on N MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                                   (= --gpus 1 --steps 100 --warmup 3; the driver passes its own K / W)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -19,8 +19,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 collected inside this process over the timed steps
   cpu_baseline  the CPU oracle (a port of the reference forward) timed on this box's host cores
                 on a bounded sample of the same workload (rank 0, N == 1 only)
-and, inside `config`, `precision`: the fp16 / strict-fp32 rates of the same step and every dtype's distance from the
-CPU oracle (descriptors and mAP), measured outside the timed region.
+and, inside `config`, measured outside the timed region (N = 1 only):
+  precision     the fp16 / fp16p (fp16 with the paired head: the compliant fast mode) / strict-fp32 rates of the same step and
+                every dtype's distance from the CPU oracle (descriptors on the calibrated checkpoint, and mAP)
+  workloads     BASELINE configs[3] and configs[4] on this GPU, a few steps each (the code of the two workloads below)
+The timed loops run with the Python cycle collector off (a full collection in the first timed step idles the GPU for 35-55 ms).
 
 Two more workloads keep the same flags and JSON contract (the default above is BASELINE configs[1]):
   --workload distractors   configs[3]: 70 x 1 006 322 x 2048 similarity + device rank / AP, the database sharded over

@@ -20,7 +20,7 @@ def make_net(head, arch, opts, sd, dtype):
     return net.eval()
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16', 'fp16p'])
 @pytest.mark.parametrize('case', HEAD_CASES, ids=[c[0] for c in HEAD_CASES])
 def test_head_vs_reference_golden(case, dtype, head_goldens):
     import dir_oracle as O
@@ -36,7 +36,7 @@ def test_head_vs_reference_golden(case, dtype, head_goldens):
     assert np.all(1 - cos < 1e-4), '%s %s: 1-cos = %s' % (tag, dtype, 1 - cos)
     if head == 'cls':
         # logits are not normalised: compare magnitudes too, against the 16-bit emulation
-        emu = head_oracle(sd, head, arch, opts, x, quant=dtype).numpy()
+        emu = head_oracle(sd, head, arch, opts, x, quant=dtype).numpy()      # (fp16p: pairs in the head, fp16 after)
         tol = 2e-2 if dtype == 'bf16' else 3e-3
         assert np.abs(got - emu).max() < tol * np.abs(emu).max()
     else:
