@@ -463,6 +463,60 @@ int dir_conv_c3c1_ds(const void* t2, const void* x, const void* wcat, const floa
     DIR_CATCH
 }
 
+int dir_conv_c3c1_wpair(const void* t2, const void* w3, const void* w3_lo, const float* bias3, const void* res, void* y,
+                        const void* w1, const void* w1_lo, const float* bias1, void* t1, int B, int H, int W, int P2,
+                        int relu3, int relu1, void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, t2, w3, bias3, res, y, B, H, W, 64, 256, 1, 1, 1, 0, H, W, relu3);
+    if (rc != DIR_OK) return rc;
+    if (!w3_lo || !w1 || !bias1 || !t1 || !res) return fail(DIR_ERR_INVALID, "conv_c3c1_wpair: null pointer");
+    a.w_lo = (const uint16_t*)w3_lo;
+    a.w2 = (const uint16_t*)w1;
+    a.w2_lo = (const uint16_t*)w1_lo;
+    a.bias2 = bias1;
+    a.y2 = (uint16_t*)t1;
+    a.Cout2 = P2;
+    a.relu2 = relu1 ? 1 : 0;
+    if (!conv_c3c1_admissible(a))
+        return fail(DIR_ERR_INVALID, "conv_c3c1_wpair: planes 64; P2 = 64 (w1_lo required) or 128 (w1_lo optional)");
+    const void* ptrs[] = {t2, w3, w3_lo, res, y, w1, w1_lo, t1, bias3, bias1};
+    for (const void* q : ptrs)
+        if ((uintptr_t)q & 15) return fail(DIR_ERR_INVALID, "conv_c3c1_wpair: tensors must be 16-byte aligned");
+    hipError_t e = conv_c3c1_launch(a, DIR_FP16, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv_c3c1_wpair launch: ") + hipGetErrorString(e));
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_conv_c3c1_ds_wpair(const void* t2, const void* x, const void* x_lo, const void* wcat, const void* wcat_lo,
+                           const float* bias, void* y, const void* w1, const void* w1_lo, const float* bias1, void* t1,
+                           int B, int H, int W, int relu3, int relu1, void* stream) {
+    DIR_TRY
+    ConvArgs a;
+    int rc = fill_conv_args(a, t2, wcat, bias, nullptr, y, B, H, W, 64, 256, 1, 1, 1, 0, H, W, relu3);
+    if (rc != DIR_OK) return rc;
+    if (!x || !x_lo || !wcat_lo || !w1 || !w1_lo || !bias1 || !t1) return fail(DIR_ERR_INVALID, "conv_c3c1_ds_wpair: null pointer");
+    a.x2 = (const uint16_t*)x;
+    a.x2_lo = (const uint16_t*)x_lo;
+    a.Cin2 = 64;
+    a.w_lo = (const uint16_t*)wcat_lo;
+    a.w2 = (const uint16_t*)w1;
+    a.w2_lo = (const uint16_t*)w1_lo;
+    a.bias2 = bias1;
+    a.y2 = (uint16_t*)t1;
+    a.Cout2 = 64;
+    a.relu2 = relu1 ? 1 : 0;
+    if (!conv_c3c1_admissible(a)) return fail(DIR_ERR_INVALID, "conv_c3c1_ds_wpair: shape not admissible");
+    const void* ptrs[] = {t2, x, x_lo, wcat, wcat_lo, y, w1, w1_lo, t1, bias, bias1};
+    for (const void* q : ptrs)
+        if ((uintptr_t)q & 15) return fail(DIR_ERR_INVALID, "conv_c3c1_ds_wpair: tensors must be 16-byte aligned");
+    hipError_t e = conv_c3c1_launch(a, DIR_FP16, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("conv_c3c1_ds_wpair launch: ") + hipGetErrorString(e));
+    return DIR_OK;
+    DIR_CATCH
+}
+
 int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* bias, void* y, int B, int OH, int OW,
                   int Cin, int Cout, int Cin2, int H2, int W2, int stride2, int relu, int dtype, void* stream) {
     DIR_TRY
@@ -486,9 +540,9 @@ int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* 
         return fail(DIR_ERR_INVALID, "conv_dual: tensor exceeds 2^31 bytes; lower the batch");
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv_dual: bad dtype");
     // (small shapes included: the op-level entry point runs the form wherever the tile divides Cout)
-    int variant = conv_pick_dual_variant(a);   // what the engine would run (the ring form where it qualifies or is forced)
-    for (int v = 0; variant < 0 && v < conv_variant_count(); ++v)
-        if (conv_variant(v).launch_dual[0] && Cout % conv_variant(v).BN == 0) variant = v;
+    // what the engine runs at batch size: the persistent two-source ring (conv_persist.hip), or conv_igemm.hip's tile under
+    // DIRTORCH_AMD_DUAL_IGEMM=1
+    const int variant = conv_pick_dual_variant(a, true);
     if (variant < 0) return fail(DIR_ERR_INVALID, "conv_dual: Cout must be a multiple of 256");
     return conv_launch(a, dtype, variant, (hipStream_t)stream);
     DIR_CATCH

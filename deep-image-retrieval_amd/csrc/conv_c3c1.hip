@@ -25,6 +25,12 @@
 // registers next to W3, and the 4P-wide residual tensor never exists (2 x 4P bytes per pixel less, one
 // launch less; one 16-bit rounding less than the reference's storage points).
 //
+// WP3 / WP1 (DIR_FP16P, fp16 only): the weights of conv3 (+ downsample) / of conv1' are fp16 PAIRS (hi + lo planes, ~22 bits:
+// csrc/conv_pair.hip); the lo planes sit in registers next to the hi ones and every product term costs a second MFMA -
+// free on these HBM-bound seams (MfmaUtil 0.13-0.24 single).  In the DS form the block input (the stem's pooled output)
+// is a pair too: its lo plane is staged as a third 64-channel K block that multiplies the downsample's HI weights (the
+// lo x lo term, 2^-22 relative, is dropped as everywhere in the paired head).
+//
 // conv1' consumes exactly the 16-bit values stored to HBM, so the result equals the two-kernel path up
 // to the fp32 summation order of the K halves.  Weights of layer3 (1 MB per seam) do not fit the 512 KB
 // register file: that seam streams them from L2 through an LDS ring instead (conv_seam3.hip).
@@ -37,17 +43,20 @@ static constexpr uint32_t kOOBf = 0x80000000u;
 
 // P2 = planes of the block that conv1' opens: P inside a stage, 2 P across the layer1 -> layer2 boundary
 // (layer2's first conv1 is 1x1 stride 1 over the 256-wide layer1 output; the stride sits in its conv2).
-template <class DT, int P, bool DS, int P2>
+template <class DT, int P, bool DS, int P2, bool WP3 = false, bool WP1 = false>
 __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     static_assert(P == 64 || P == 128, "planes");
     static_assert(P2 == P || (P == 64 && P2 == 128), "conv1' width");
     static_assert(!DS || (P == 64 && P2 == 64), "the downsample form is layer1's: 64 + 64 input channels");
-    constexpr int KA = P + (DS ? 64 : 0);       // phase A contraction length (t2 channels [+ block input])
+    static_assert((!WP3 && !WP1) || P == 64, "paired weights: layer1's seams");
+    constexpr int KW = P + (DS ? 64 : 0);       // contraction length of the weight matrix (t2 channels [+ block input])
+    constexpr int KA = KW + (DS && WP3 ? 64 : 0);   // ... of the staged tile: + the block input's lo plane
     constexpr int C4 = 4 * P;                   // block width
     constexpr int BM = 64, NT = 512;
     constexpr int CW = C4 / 8;                  // phase A: output channels per wave (32 / 64)
     constexpr int TA = CW / 32;                 // ... as 32-channel MFMA tiles (1 / 2)
-    constexpr int KSA = KA / 16;                // phase A k-slices (4 / 8)
+    constexpr int KSA = KA / 16;                // phase A k-slices (4 / 8 / 12)
+    constexpr int KSW = KW / 16;                // ... that have weights of their own
     constexpr int XBUF = BM * KA * 2;           // one t2 (+ x) tile: KA/64 blocks of [64 px][128 B]
     constexpr int NX = XBUF / 16 / NT;          // staging loads per lane per tile (1 / 2)
     constexpr int EROW = 32 * 4 + 16;           // staging row: 32 fp32 + pad
@@ -69,6 +78,9 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x2 =      // DS: the block input [M][64]
         __builtin_amdgcn_make_buffer_rsrc((void*)(DS ? a.x2 : a.x), 0, DS ? (uint32_t)((size_t)a.M * 128) : a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2l =     // DS + WP3: its lo plane
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DS && WP3 ? a.x2_lo : a.x), 0,
+                                          DS && WP3 ? (uint32_t)((size_t)a.M * 128) : a.x_bytes, 0x00020000);
     const uint32_t y_bytes = (uint32_t)((size_t)a.M * C4 * 2);
     const uint32_t y2_bytes = (uint32_t)((size_t)a.M * P2 * 2);
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, y_bytes, 0x00020000);
@@ -83,29 +95,41 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     const int n_wave = wave * CW;               // phase A: first output channel of this wave
 
     // ---- weights -> registers, once --------------------------------------------------------------
-    frag_t w3[TA][KSA];
+    frag_t w3[TA][KSW], w3l[WP3 ? TA : 1][WP3 ? KSW : 1];
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int ks = 0; ks < KSA; ++ks)
-            w3[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + i * 32 + lrow) * KA + ks * 16 + 8 * lhi);
+        for (int ks = 0; ks < KSW; ++ks) {
+            w3[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + i * 32 + lrow) * KW + ks * 16 + 8 * lhi);
+            if (WP3)
+                w3l[i][ks] = *(const DIR_GLOBAL frag_t*)(a.w_lo + (size_t)(n_wave + i * 32 + lrow) * KW + ks * 16 + 8 * lhi);
+        }
     // phase B roles: P2 = 128: (n-tile = w & 3, K half = w >> 2), both 32-pixel strips;
     //                P2 =  64: (n-tile = w & 1, strip = (w >> 1) & 1, K half = w >> 2)
     constexpr bool WIDE = P2 == 128;
     const int nt = WIDE ? (wave & 3) : (wave & 1);
     const int kh = wave >> 2;
     const int jb = WIDE ? 0 : ((wave >> 1) & 1);
-    frag_t w1[KSB];
+    frag_t w1[KSB], w1l[WP1 ? KSB : 1];
 #pragma unroll
-    for (int ks = 0; ks < KSB; ++ks)
+    for (int ks = 0; ks < KSB; ++ks) {
         w1[ks] = *(const DIR_GLOBAL frag_t*)(a.w2 + (size_t)(nt * 32 + lrow) * C4 + kh * (C4 / 2) + ks * 16 + 8 * lhi);
+        if (WP1)
+            w1l[ks] = *(const DIR_GLOBAL frag_t*)(a.w2_lo + (size_t)(nt * 32 + lrow) * C4 + kh * (C4 / 2) + ks * 16 + 8 * lhi);
+    }
     // pin: the waits for these loads must not be re-executed inside the loop (conv_wreg.hip)
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
-        for (int ks = 0; ks < KSA; ++ks) asm volatile("" : "+v"(w3[i][ks]));
+        for (int ks = 0; ks < KSW; ++ks) {
+            asm volatile("" : "+v"(w3[i][ks]));
+            if (WP3) asm volatile("" : "+v"(w3l[i][ks]));
+        }
 #pragma unroll
-    for (int ks = 0; ks < KSB; ++ks) asm volatile("" : "+v"(w1[ks]));
+    for (int ks = 0; ks < KSB; ++ks) {
+        asm volatile("" : "+v"(w1[ks]));
+        if (WP1) asm volatile("" : "+v"(w1l[ks]));
+    }
 
     // ---- per-lane constants -----------------------------------------------------------------------
     const int spix = (tid >> 3) & 63, sslot = tid & 7;                    // t2 staging: row, 16-byte chunk
@@ -124,9 +148,10 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
     auto load_x = [&](int t, u32x4_t* xr) {
         const int m = t * BM + spix;
         const uint32_t base = m < a.M ? (uint32_t)((m * P + sslot * 8) * 2) : kOOBf;
-        if (DS) {   // block 0 = t2 row, block 1 = block-input row (both 64 channels = 128 bytes per pixel)
+        if (DS) {   // block 0 = t2 row, block 1 = block-input row [, block 2 = its lo plane] (64 channels = 128 bytes each)
             xr[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, 0, 0);
-            xr[NX - 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2, base, 0, 0);
+            xr[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2, base, 0, 0);
+            if (WP3) xr[NX - 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2l, base, 0, 0);
         } else {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, i * 128, 0);
@@ -175,8 +200,13 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
             for (int ks = 0; ks < KSA; ++ks) {
                 const frag_t xf = *(const frag_t*)(xb + (ks >> 2) * (BM * 128) + j * (32 * 128) + lbase +
                                                    (((2 * (ks & 3) + lhi) ^ lswz) << 4));
+                // (K block 2 of the paired DS form = the block input's lo plane: the downsample's hi weights once more)
+                const int kw = ks < KSW ? ks : ks - 4;
 #pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i] = DT::mfma32(w3[i][ks], xf, acc[i]);
+                for (int i = 0; i < TA; ++i) {
+                    acc[i] = DT::mfma32(w3[i][kw], xf, acc[i]);
+                    if (WP3 && ks < KSW) acc[i] = DT::mfma32(w3l[i][ks], xf, acc[i]);
+                }
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             if (!DS) {
@@ -256,6 +286,7 @@ __global__ void __launch_bounds__(512) conv_c3c1_kernel(const ConvArgs a) {
                     const frag_t of = *(const frag_t*)(otile + kb * (BM * 128) + j * (32 * 128) + lbase +
                                                        (((2 * (ks & 3) + lhi) ^ lswz) << 4));
                     acc1[jj] = DT::mfma32(w1[ks], of, acc1[jj]);
+                    if (WP1) acc1[jj] = DT::mfma32(w1l[ks], of, acc1[jj]);
                 }
                 if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -337,15 +368,19 @@ bool conv_c3c1_admissible(const ConvArgs& a) {
            (a.Cin == 64 || a.Cin == 128) && a.Cout == 4 * a.Cin && (ds ? (a.res == nullptr && a.Cin == 64 && a.Cin2 == 64)
                                                                        : a.res != nullptr) &&
            a.w2 != nullptr && a.bias2 != nullptr && a.y2 != nullptr &&
-           (a.Cout2 == a.Cin || (!ds && a.Cin == 64 && a.Cout2 == 128)) && (long)a.M * a.Cout < (1L << 30);
+           (a.Cout2 == a.Cin || (!ds && a.Cin == 64 && a.Cout2 == 128)) && (long)a.M * a.Cout < (1L << 30) &&
+           // paired weights (DIR_FP16P): layer1's seams; conv3's are pairs whenever anything is, and the block input of the
+           // DS form comes with its lo plane exactly then
+           ((!a.w_lo && !a.w2_lo && !a.x2_lo) ||
+            (a.Cin == 64 && a.w_lo && (a.w2_lo || a.Cout2 == 128) && (ds ? a.x2_lo != nullptr : a.x2_lo == nullptr)));
 }
 
-template <class DT, int P, bool DS, int P2 = P>
+template <class DT, int P, bool DS, int P2 = P, bool WP3 = false, bool WP1 = false>
 static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
-    constexpr int XBUF = 64 * (P + (DS ? 64 : 0)) * 2;
+    constexpr int XBUF = 64 * (P + (DS ? 64 : 0) + (DS && WP3 ? 64 : 0)) * 2;
     constexpr int LDS = 2 * XBUF + 8 * 32 * (32 * 4 + 16) + 64 * 4 * P * 2 + (4 * P + P2) * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_c3c1_kernel<DT, P, DS, P2>;
+    auto kern = conv_c3c1_kernel<DT, P, DS, P2, WP3, WP1>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -358,6 +393,14 @@ static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
 
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
     if (a.Cin == 256) return conv_seam3_launch(a, dtype, stream);
+    if (a.w_lo) {   // DIR_FP16P: conv3's (+ downsample's) weights are pairs; conv1's are when they belong to layer1 too
+        if (dtype != DIR_FP16) return hipErrorInvalidValue;
+        if (a.x2) return a.w2_lo ? launch_c3c1<FP16, 64, true, 64, true, true>(a, stream) : hipErrorInvalidValue;
+        if (a.Cout2 == 128)
+            return a.w2_lo ? launch_c3c1<FP16, 64, false, 128, true, true>(a, stream)
+                           : launch_c3c1<FP16, 64, false, 128, true, false>(a, stream);
+        return a.w2_lo ? launch_c3c1<FP16, 64, false, 64, true, true>(a, stream) : hipErrorInvalidValue;
+    }
     if (a.x2)
         return dtype == DIR_BF16 ? launch_c3c1<BF16, 64, true>(a, stream) : launch_c3c1<FP16, 64, true>(a, stream);
     if (a.Cin == 128)

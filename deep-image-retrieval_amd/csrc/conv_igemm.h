@@ -40,6 +40,7 @@ struct ConvArgs {
     const uint16_t* x_lo;
     const uint16_t* x2_lo;   // ... and of the second K source (x2) in the two-source form
     const uint16_t* w_lo;
+    const uint16_t* w2_lo;   // the fused seam (conv_c3c1.hip, WP1): lo plane of the following conv1's weights
     const uint16_t* res_lo;
     uint16_t* y_lo;
     // filled by the launcher
@@ -74,6 +75,8 @@ struct ConvVariant {
 
 bool conv1x1_persist_admissible(const ConvArgs& a);
 hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream, bool xdeep = false);
+hipError_t conv1x1_persist_dual_bf16(const ConvArgs& a, hipStream_t stream);   // conv3 + downsample, two K sources
+hipError_t conv1x1_persist_dual_fp16(const ConvArgs& a, hipStream_t stream);
 bool conv_patch64_lc_admissible(const ConvArgs& a);
 hipError_t conv_patch64_lc_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_ring_admissible(const ConvArgs& a);
@@ -103,7 +106,7 @@ const ConvVariant& conv_variant(int i);
 bool conv_variant_admissible(int v, const ConvArgs& a);
 int conv_pick_variant(const ConvArgs& a);
 // Variant for the two-source form (a.x2 set), or -1 when none fits the shape.
-int conv_pick_dual_variant(const ConvArgs& a);
+int conv_pick_dual_variant(const ConvArgs& a, bool any_size = false);
 int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream);
 // Split factor for variant `v` on problem `a` (1 = none) and the fp32 scratch it needs.
 int conv_splitk_factor(int v, const ConvArgs& a);

@@ -513,7 +513,9 @@ static const ConvVariant kVariants[] = {
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}, {nullptr, nullptr}},
     // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
-    {"256x256_persist1x1_x3", 256, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 4, {nullptr, nullptr}, {nullptr, nullptr}},
+    // ... and its two-source form (conv3 + downsample of the first block of layers 2-4)
+    {"256x256_persist1x1_x3", 256, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 4, {nullptr, nullptr},
+     {conv1x1_persist_dual_bf16, conv1x1_persist_dual_fp16}},
     // persistent 128x256 tile, loader waves feed ONE three-slot K ring over all the tiles of a workgroup, consumer waves
     // multiply; 1x1 convs without a residual (conv_ring.hip)
     {"128x256_ring1x1", 128, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 7, {nullptr, nullptr}, {nullptr, nullptr}},
@@ -642,7 +644,7 @@ int conv_pick_variant(const ConvArgs& a) {
 }
 
 // Two-source form: which of the DUAL instantiations runs a given conv3 + downsample pair.
-int conv_pick_dual_variant(const ConvArgs& a) {
+int conv_pick_dual_variant(const ConvArgs& a, bool any_size) {
     const bool ok = a.x2 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
                     a.Cin % 64 == 0 && a.Cin2 % 64 == 0 && a.res == nullptr && a.ksplit <= 1;
     if (!ok) return -1;
@@ -653,8 +655,12 @@ int conv_pick_dual_variant(const ConvArgs& a) {
     // (a two-source form of the split loader / consumer ring, conv_ring.hip, was measured in round 3 - bit-identical,
     // 0.357 / 0.267 / 0.224 ms against 0.342 / 0.254 / 0.215 ms for this one-role tile: four consumer waves multiply slower
     // than eight and these GEMMs are not memory-bound enough for the overlap to pay - and retired in round 4)
-    if (a.Cout % 256 != 0 || (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192) return -1;
-    const int v = find_variant("256x256_w4x2");
+    // (any_size: the op-level entry point runs the form on small shapes too - the tests')
+    if (a.Cout % 256 != 0 || (!any_size && (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192)) return -1;
+    // round 4: the persistent deep-X ring with a second pixel source (conv_persist.hip DUAL); DIRTORCH_AMD_DUAL_IGEMM=1
+    // restores the one-tile-per-workgroup tile (A/B and bisecting; read per call: the tests flip it)
+    const bool igemm_dual = getenv("DIRTORCH_AMD_DUAL_IGEMM") != nullptr;
+    const int v = find_variant(igemm_dual ? "256x256_w4x2" : "256x256_persist1x1_x3");
     if (v < 0 || kVariants[v].launch_dual[0] == nullptr || a.Cout % kVariants[v].BN != 0) return -1;
     return v;
 }

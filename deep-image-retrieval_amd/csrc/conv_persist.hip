@@ -37,8 +37,14 @@ __device__ __forceinline__ uint32_t fast_div_q(uint32_t n, uint32_t mul, uint32_
 //   X runs two K-steps ahead and W one (issue order W(t+1), X(t+2); the wait before step t leaves exactly
 //   X(t+1) - the newest ops, all of the LDS-DMA kind - in flight), so 64-96 KB of HBM requests per CU
 //   are outstanding.  Next tile's W(0) / X(0) still go out before the epilogue, X(1) right after it.
-template <class DT, bool XDEEP, bool RES>
+// DUAL (deep-X form only, round 4): the K dimension comes from TWO tensors - K-steps [0, Cin/64) from x (flat: the
+// conv3 input t2), the rest from x2 (the block input, gathered at stride2: the 1x1 downsample) - against weights and
+// biases concatenated / summed at finalize: relu([W3 | Wds] . [t2 ; x_s] + b3 + bds), the first block of layers 2-4
+// (resnet.py:78-85 with :134-141) as ONE persistent GEMM.  conv_igemm.hip's DUAL tile runs the same GEMM one tile per
+// workgroup, fill and epilogue exposed on every one of its 6-24 K-steps-short tiles.
+template <class DT, bool XDEEP, bool RES, bool DUAL = false>
 __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) {
+    static_assert(!DUAL || (XDEEP && !RES), "the two-source form rides on the deep-X ring");
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int TM = 2, TN = 4;              // wave tile 64 pixels x 128 channels (4 x 2 waves)
     constexpr int NA = 4, NB = 4;              // DMA instructions per lane per stage (X, W)
@@ -61,11 +67,14 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x2 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : a.x_bytes, 0x00020000);
 
     const int ntiles = a.tiles_m * a.tiles_n;
     const int T = a.T;
+    const int T1 = DUAL ? a.Cin / 64 : 0;      // K-steps served by the first source
 
-    uint32_t xvoff[NA], wvoff[NB];
+    uint32_t xvoff[NA], wvoff[NB], xvoff2[DUAL ? NA : 1];
     // per-lane DMA offsets of a tile (1x1: one tap, padding-free; the row mask is folded in)
     auto tile_offsets = [&](int tile) {
         const int tile_n = tile % a.tiles_n, tile_m = a.rev_m ? a.tiles_m - 1 - tile / a.tiles_n : tile / a.tiles_n;
@@ -85,12 +94,28 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
                                   srcchunk * 8) * 2);
             }
             xvoff[i] = m < a.M ? off : kOOBq;
+            if (DUAL) {   // output pixel -> pixel (oh * stride2, ow * stride2) of the second source
+                const uint32_t mm = m < a.M ? (uint32_t)m : 0u;
+                const uint32_t b = fast_div_q(mm, a.div_ohw_mul, a.div_ohw_shr);
+                const uint32_t rem = mm - b * (uint32_t)(a.OH * a.OW);
+                const uint32_t oh = fast_div_q(rem, a.div_ow_mul, a.div_ow_shr);
+                const uint32_t ow = rem - oh * (uint32_t)a.OW;
+                const uint32_t off2 = (uint32_t)((((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.Cin2 +
+                                                  srcchunk * 8) * 2);
+                xvoff2[DUAL ? i : 0] = m < a.M ? off2 : kOOBq;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             wvoff[i] = (uint32_t)(((tile_n * BN + i * 64 + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
     };
     auto issue_x = [&](int t, char* dst) {
+        if (DUAL && t >= T1) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                dma16q(rsrc_x2, dst + (i * NT + wave * 64) * 16, xvoff2[DUAL ? i : 0], (t - T1) * 128);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) dma16q(rsrc_x, dst + (i * NT + wave * 64) * 16, xvoff[i], t * 128);
     };
@@ -316,13 +341,13 @@ bool conv1x1_persist_admissible(const ConvArgs& a) {
     return a.R == 1 && a.S == 1 && a.pad == 0 && a.Cout % 256 == 0 && a.Cin % 64 == 0 && a.Cin >= 128;
 }
 
-template <class DT, bool XDEEP>
+template <class DT, bool XDEEP, bool DUAL = false>
 static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     // 2-slot map: slot 0 + staging (covers slot 1); deep-X map: 3 X slots + 2 W slots = all 160 KiB
     constexpr int LDS = XDEEP ? 5 * 256 * 128 : (256 + 256) * 128 + 8 * 32 * (2 * 128 + 16);
     static_assert(LDS >= 2 * (256 + 256) * 128 && LDS <= 160 * 1024, "LDS map");
     static_assert(!XDEEP || 256 * 128 + 8 * 32 * (2 * 128 + 16) <= 3 * 256 * 128 + 256 * 128, "staging must end below W slot 1");
-    auto kern = conv1x1_persist_kernel<DT, XDEEP, !XDEEP>;
+    auto kern = conv1x1_persist_kernel<DT, XDEEP, !XDEEP, DUAL>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -331,6 +356,7 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     b.tiles_n = a.Cout / 256;
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
+    if (DUAL) b.x2_bytes = (uint32_t)((size_t)a.B * a.H2 * a.W2 * a.Cin2 * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
     static const bool no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting (read once)
     b.no_xcd_map = no_xcd_map;
@@ -350,6 +376,10 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, b);
     return hipGetLastError();
 }
+
+// the two-source form: a = the conv3 (1x1 stride 1 over t2) with x2 / Cin2 / H2 / W2 / stride2 set (conv_igemm.hip's DUAL contract)
+hipError_t conv1x1_persist_dual_bf16(const ConvArgs& a, hipStream_t stream) { return launch_persist<BF16, true, true>(a, stream); }
+hipError_t conv1x1_persist_dual_fp16(const ConvArgs& a, hipStream_t stream) { return launch_persist<FP16, true, true>(a, stream); }
 
 hipError_t conv1x1_persist_launch(const ConvArgs& a, int dtype, hipStream_t stream, bool xdeep) {
     if (xdeep) return dtype == DIR_BF16 ? launch_persist<BF16, true>(a, stream) : launch_persist<FP16, true>(a, stream);

@@ -62,6 +62,12 @@ struct dir_engine {
     int dtype = DIR_BF16;
     // DIR_FP16P: how many leading blocks (all of layer1 by default) run on fp16 pairs (conv_pair.hip); the stem always does
     int pair_blocks = 0;
+    // ... and which tensors there are pairs.  false (bottleneck nets, the default): the image, the stem (weights and
+    // output) and the 1x1 WEIGHTS of those blocks - lo planes that sit in registers of the HBM-bound seam kernels and cost
+    // MFMAs only; activations and the 3x3 weights stay single fp16 planes (1 - cos 4.2e-5 / 3.0e-5 at config A / B).
+    // true (DIRTORCH_AMD_PAIR_ACTS=1 at finalize, and always for BasicBlock nets, whose layer1 has no 1x1): every
+    // weight and every tensor INSIDE those blocks (t1, t2, the downsample branch) is a pair too (1.7e-5 / 1.5e-5).
+    bool pair_acts = false;
     // the 16-bit kernels' dtype: DIR_FP16P stores and multiplies fp16 everywhere, pairs of them in the head
     int kdtype() const { return dtype == DIR_FP16P ? DIR_FP16 : dtype; }
     bool finalized = false;
@@ -108,11 +114,13 @@ struct dir_engine {
     // output (hi plane only: what layer2 reads) in *cur and reports the map size and the next block index
     int forward_pair_head(const void* img, int B, int H, int W, int fmt, char* base, const dir::Plan& p,
                           hipStream_t stream, uint16_t** cur, int* h, int* w, size_t* next_block);
+    // its first two launches: image -> paired space-to-depth image -> paired pooled stem output (hi: bufA, lo: lo_stem)
+    int forward_pair_stem(const void* img, int B, int H, int W, int fmt, char* base, const dir::Plan& p, hipStream_t stream);
     // conv3 of one bottleneck + conv1 of the next in one kernel (conv_c3c1.hip); *used = 0 when the shapes
     // do not qualify and nothing was launched
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
                  uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
-                 const uint16_t* block_in = nullptr);
+                 const uint16_t* block_in = nullptr, const uint16_t* block_in_lo = nullptr);
     // conv3 + the block's 1x1 downsample branch as ONE two-source GEMM (conv_igemm.hip DUAL form); dry = only
     // report whether it would run (decided before the downsample would be launched)
     int run_conv_dual(dir::ConvLayer& c3, const dir::ConvLayer& ds, const uint16_t* t2, const uint16_t* xin,

@@ -135,8 +135,10 @@ int dir_engine::finalize(int dt) {
     auto to16 = [&](float f) { return dt == DIR_BF16 ? f32_to_bf16_bits(f) : f32_to_f16_bits(f); };
     // DIR_FP16P: the stem and the first pair_blocks residual blocks keep their weights as fp16 PAIRS (conv_pair.hip).
     // Default = all of layer1 (where tests/precision_decomposition.py puts the 16-bit error of a conditioned network);
-    // DIRTORCH_AMD_PAIR_STAGES = 1..4 moves the boundary to the end of that stage.
+    // DIRTORCH_AMD_PAIR_STAGES = 1..4 moves the boundary to the end of that stage.  Which weights: every conv of those
+    // blocks with pair_acts (engine.h), else their 1x1s only.
     pair_blocks = 0;
+    pair_acts = !desc.bottleneck || getenv("DIRTORCH_AMD_PAIR_ACTS") != nullptr;
     std::vector<char> is_pair(convs.size(), 0);
     if (dt == DIR_FP16P) {
         int stages = 1;
@@ -150,7 +152,7 @@ int dir_engine::finalize(int dt) {
         for (int bi = 0; bi < pair_blocks; ++bi) {
             const BlockDef& bd = blocks[bi];
             for (int ci : {bd.conv1, bd.conv2, bd.conv3, bd.down})
-                if (ci >= 0) is_pair[ci] = 1;
+                if (ci >= 0 && (pair_acts || (convs[ci].R == 1 && convs[ci].S == 1))) is_pair[ci] = 1;
         }
     }
 
@@ -395,10 +397,10 @@ int dir_engine::plan(int B, int H, int W, Plan* p) const {
     p->ds = take(ds ? ds : 256);
     p->x4 = take(x4 ? x4 : 256);
     p->lo_s2d = p->lo_stem = p->lo_t1 = p->lo_t2 = p->lo_ds = 0;
-    if (dtype == DIR_FP16P) {   // lo planes of the paired head: image, stem output, t1 / t2 / downsample of its blocks
+    if (dtype == DIR_FP16P) {   // lo planes of the paired head: image, stem output [, t1 / t2 / downsample of its blocks]
         size_t pt1 = 0, pt2 = 0, pds = 0;
         int ph = p->PH, pw = p->PW;
-        for (int bi = 0; bi < pair_blocks && bi < (int)blocks.size(); ++bi) {
+        for (int bi = 0; pair_acts && bi < pair_blocks && bi < (int)blocks.size(); ++bi) {
             const BlockDef& bd = blocks[bi];
             const int oh = conv_out(ph, 3, bd.stride, 1), ow = conv_out(pw, 3, bd.stride, 1);
             const ConvLayer& c1 = convs[bd.conv1];
@@ -453,6 +455,9 @@ int dir_engine::prof_end(hipStream_t stream) {
 // ---- one convolution ----------------------------------------------------------------------------
 int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, uint16_t* y, int B,
                          int H, int W, int OH, int OW, hipStream_t stream, bool rev_m) {
+    // DIR_FP16P: a layer whose weights are a pair multiplies both planes (conv_pair.hip; single-plane input and output here)
+    if (dtype == DIR_FP16P && L.d_w_lo && !L.stem)
+        return run_conv_pair(L, x, nullptr, res, nullptr, y, nullptr, B, H, W, OH, OW, stream);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.rev_m = rev_m ? 1 : 0;
@@ -602,18 +607,10 @@ int dir_engine::run_conv_pair(ConvLayer& L, const uint16_t* x, const uint16_t* x
 // ---- DIR_FP16P: image -> stem -> the paired residual blocks ---------------------------------------------------------
 // The reference's op sequence (ResNet.forward resnet.py:157-161, Bottleneck.forward :67-87 / BasicBlock :29-44), nothing
 // fused across layers; every tensor two fp16 planes (hi in the ordinary workspace regions, lo in the lo_* regions).
-int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt, char* base, const Plan& p,
-                                  hipStream_t stream, uint16_t** cur_out, int* h_out, int* w_out, size_t* next_block) {
+int dir_engine::forward_pair_stem(const void* img, int B, int H, int W, int fmt, char* base, const Plan& p,
+                                  hipStream_t stream) {
     uint16_t* s2d = (uint16_t*)(base + p.s2d);
     uint16_t* s2d_lo = (uint16_t*)(base + p.lo_s2d);
-    uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
-    uint16_t* stem_lo = (uint16_t*)(base + p.lo_stem);
-    uint16_t* t1 = (uint16_t*)(base + p.t1);
-    uint16_t* t2 = (uint16_t*)(base + p.t2);
-    uint16_t* ds = (uint16_t*)(base + p.ds);
-    uint16_t* t1_lo = (uint16_t*)(base + p.lo_t1);
-    uint16_t* t2_lo = (uint16_t*)(base + p.lo_t2);
-    uint16_t* ds_lo = (uint16_t*)(base + p.lo_ds);
     int rc;
     if (img) {
         rc = prof_begin("prep_input", "prep_input_pair", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
@@ -628,17 +625,31 @@ int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt,
         DIR_HIP_CHECK(hipGetLastError());
         DIR_HIP_CHECK(hipMemsetAsync(s2d_lo, 0, (size_t)n * 2, stream));
     }
-    int cur = 0;
     rc = prof_begin("conv1+maxpool", "stem_pool_pair", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
                     4.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256), stream);
     if (rc != DIR_OK) return rc;
-    rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, pp[cur], stem_lo, B, p.H2, p.W2,
-                               p.OH1, p.OW1, stream, d_ovf);
+    rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, (uint16_t*)(base + p.bufA),
+                               (uint16_t*)(base + p.lo_stem), B, p.H2, p.W2, p.OH1, p.OW1, stream, d_ovf);
     if (rc != DIR_OK) return rc;
-    if ((rc = prof_end(stream)) != DIR_OK) return rc;
+    return prof_end(stream);
+}
 
-    // Which tensors are pairs (tests/precision_decomposition.py prices every storage point): the image, the stem output
-    // and everything INSIDE a block (t1, t2, the downsample branch) - the block outputs, 4P wide and read three times
+int dir_engine::forward_pair_head(const void* img, int B, int H, int W, int fmt, char* base, const Plan& p,
+                                  hipStream_t stream, uint16_t** cur_out, int* h_out, int* w_out, size_t* next_block) {
+    uint16_t* const pp[2] = {(uint16_t*)(base + p.bufA), (uint16_t*)(base + p.bufB)};
+    uint16_t* stem_lo = (uint16_t*)(base + p.lo_stem);
+    uint16_t* t1 = (uint16_t*)(base + p.t1);
+    uint16_t* t2 = (uint16_t*)(base + p.t2);
+    uint16_t* ds = (uint16_t*)(base + p.ds);
+    uint16_t* t1_lo = (uint16_t*)(base + p.lo_t1);
+    uint16_t* t2_lo = (uint16_t*)(base + p.lo_t2);
+    uint16_t* ds_lo = (uint16_t*)(base + p.lo_ds);
+    int rc = forward_pair_stem(img, B, H, W, fmt, base, p, stream);
+    if (rc != DIR_OK) return rc;
+    int cur = 0;
+
+    // pair_acts form.  Which tensors are pairs (tests/precision_decomposition.py prices every storage point): the image,
+    // the stem output and everything INSIDE a block (t1, t2, the downsample branch) - the block outputs, 4P wide and read three times
     // each, are single fp16 planes: their rounding costs 7e-6 of the 1e-4 budget and a third of the head's bytes.
     int h = p.PH, w = p.PW;
     const size_t nb = std::min((size_t)pair_blocks, blocks.size());
@@ -695,7 +706,7 @@ static constexpr long kSeam3MinTiles = 768;   // conv_seam3.hip: three 64-pixel 
 
 int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
                          uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
-                         const uint16_t* block_in) {
+                         const uint16_t* block_in, const uint16_t* block_in_lo) {
     *used = 0;
     // DIRTORCH_AMD_C3C1: "0" = never (A/B and bisecting), "force" = whenever the shapes qualify, default =
     // when every persistent workgroup gets at least ~8 pixel tiles to amortise loading both weight sets
@@ -704,15 +715,20 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     memset(&a, 0, sizeof(a));
     a.x = t2;
     a.w = c3.d_w;
+    a.w_lo = c3.d_w_lo;       // DIR_FP16P: the weights of layer1's 1x1s are pairs (conv_c3c1.hip WP3 / WP1)
+    a.w2_lo = c1.d_w_lo;
     a.bias = c3.d_bias;
     a.res = res;
     if (block_in) {   // DS form: the residual is the downsample conv of the block input, folded into this GEMM
         if (!c3.d_w_ds || c3.Cin != 64) return DIR_OK;   // (the caller checks the downsample's own shape)
         a.w = c3.d_w_ds;
+        a.w_lo = c3.d_w_ds_lo;
         a.bias = c3.d_bias_ds;
         a.res = nullptr;
         a.x2 = block_in;
+        a.x2_lo = block_in_lo;
         a.Cin2 = 64;
+        if ((c3.d_w_lo != nullptr) != (a.w_lo != nullptr)) return DIR_OK;   // (a paired conv3 without the concatenated lo plane)
     }
     a.y = y;
     a.B = B;
@@ -739,13 +755,14 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
     if (!sw.c3c1_force && (a.M + 63) / 64 < (a.Cin == 256 ? kSeam3MinTiles : kSeamMinTiles)) return DIR_OK;
     if (a.Cin == 256 && sw.no_seam3) return DIR_OK;
     const double macs = (double)a.M * ((double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
-    const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
-                                (double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
+    const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 * (block_in_lo ? 2 : 1) + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
+                                (double)c3.Cout * (c3.Cin + a.Cin2) * (a.w_lo ? 2 : 1) + (double)c1.Cout * c1.Cin * (a.w2_lo ? 2 : 1));
     // profile row "layerS.J.c3c1": conv3 of block J + conv1 of block J+1
     int rc = DIR_OK;
     if (profiling && !prof_paused)
         rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + (block_in ? ".ds+c3c1" : ".c3c1"),
-                        (c3.Cin == 256 ? "conv_seam3<" : "conv_c3c1<") + std::to_string(c3.Cin) + (block_in ? ",ds>" : ">"),
+                        (c3.Cin == 256 ? "conv_seam3<" : "conv_c3c1<") + std::to_string(c3.Cin) + (block_in ? ",ds" : "") +
+                            (a.w_lo ? ",wp>" : ">"),
                         2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     hipError_t e = conv_c3c1_launch(a, kdtype(), stream);
@@ -759,7 +776,7 @@ int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t
                               uint16_t* y, int B, int Hin, int Win, int OH, int OW, hipStream_t stream, int* used,
                               bool dry) {
     *used = 0;
-    if (!c3.d_w_ds || sw.no_dual) return DIR_OK;
+    if (!c3.d_w_ds || sw.no_dual || c3.d_w_lo) return DIR_OK;   // (paired weights: conv_pair.hip has no strided two-source form)
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = t2;
@@ -846,10 +863,18 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     const int kd = kdtype();
     int h = 0, w = 0;
     size_t first_block = 0;
-    if (dtype == DIR_FP16P) {
+    const uint16_t* cur_lo = nullptr;   // lo plane of the block input (DIR_FP16P: the stem's pooled output)
+    if (dtype == DIR_FP16P && pair_acts) {
         // 1-2'. paired head: image, stem and the first pair_blocks residual blocks on fp16 pairs (conv_pair.hip)
         rc = forward_pair_head(img, B, H, W, fmt, base, p, stream, &cur, &h, &w, &first_block);
         if (rc != DIR_OK) return rc;
+    } else if (dtype == DIR_FP16P) {
+        // 1-2''. image and stem on pairs; the blocks run below on single fp16 planes, with paired 1x1 WEIGHTS in layer1
+        rc = forward_pair_stem(img, B, H, W, fmt, base, p, stream);
+        if (rc != DIR_OK) return rc;
+        cur_lo = (const uint16_t*)(base + p.lo_stem);
+        h = p.PH;
+        w = p.PW;
     } else {
         // 1. image -> space-to-depth NHWC16
         if (img) {
@@ -918,18 +943,20 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         }
         // the other stages' first blocks: conv3 + downsample as one two-source GEMM (conv_igemm.hip, DUAL)
         int ds_dual = 0;
-        if (bd.down >= 0 && !ds_in_seam && desc.bottleneck && !tuning) {
+        if (bd.down >= 0 && !ds_in_seam && desc.bottleneck && !tuning && !cur_lo) {
             rc = run_conv_dual(convs[bd.conv3], convs[bd.down], t2, cur, nxt, B, h, w, oh, ow, stream, &ds_dual, true);
             if (rc != DIR_OK) return rc;
         }
         if (bd.down >= 0 && !ds_in_seam && !ds_dual) {
-            rc = run_conv(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
+            rc = cur_lo ? run_conv_pair(convs[bd.down], cur, cur_lo, nullptr, nullptr, ds, nullptr, B, h, w, oh, ow, stream)
+                        : run_conv(convs[bd.down], cur, nullptr, ds, B, h, w, oh, ow, stream);
             if (rc != DIR_OK) return rc;
             resid = ds;
         }
         if (desc.bottleneck) {
             if (!t1_ready) {   // (the previous block's fused seam kernel may have produced t1 already)
-                rc = run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream, sw.rev_conv1);
+                rc = cur_lo ? run_conv_pair(convs[bd.conv1], cur, cur_lo, nullptr, nullptr, t1, nullptr, B, h, w, h, w, stream)
+                            : run_conv(convs[bd.conv1], cur, nullptr, t1, B, h, w, h, w, stream, sw.rev_conv1);
                 if (rc != DIR_OK) return rc;
             }
             t1_ready = false;
@@ -944,7 +971,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             } else if (seam_next) {
                 // conv3 + the next block's conv1 in one kernel: the block output is not re-read (conv_c3c1.hip)
                 rc = run_seam(convs[bd.conv3], convs[blocks[bi + 1].conv1], t2, resid, nxt, t1, B, oh, ow, stream,
-                              &fused, ds_in_seam ? cur : nullptr);
+                              &fused, ds_in_seam ? cur : nullptr, ds_in_seam ? cur_lo : nullptr);
                 if (rc != DIR_OK) return rc;
                 if (ds_in_seam && !fused) return fail(DIR_ERR_STATE, "seam kernel declined a downsample it was promised");
             }
@@ -961,6 +988,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             if (rc != DIR_OK) return rc;
         }
         cur = nxt;
+        cur_lo = nullptr;   // block outputs are single planes in every mode
         h = oh;
         w = ow;
         if (keep) {

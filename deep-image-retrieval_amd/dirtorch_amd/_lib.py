@@ -80,6 +80,8 @@ SIGNATURES = {
                       + [c_int] * 8 + [c_void_p]),
     'dir_conv_c3c1_ds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                          + [c_int] * 6 + [c_void_p]),
+    'dir_conv_c3c1_wpair': (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_void_p]),
+    'dir_conv_c3c1_ds_wpair': (c_int, [c_void_p] * 11 + [c_int] * 5 + [c_void_p]),
     'dir_conv_dual': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     'dir_conv_bn_act_naive': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
                               + [c_int] * 13 + [c_void_p]),

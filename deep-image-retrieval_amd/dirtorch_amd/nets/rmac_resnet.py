@@ -30,12 +30,16 @@ def _default_dtype():
     """Storage format of activations and weights (accumulation is always fp32); DIRTORCH_AMD_DTYPE or
     net.compute_dtype:
 
-      fp16p (default) fp16 with a PAIRED head: the image, the stem and layer1 - where a conditioned network makes ~94 % of
-            its 16-bit rounding error (tests/precision_decomposition.py) - run on pairs of fp16 values (hi + lo, ~22 bits,
-            three MFMAs per product: conv_pair.hip), layers 2-4 on the fp16 kernels.  1.7e-5 of descriptor cosine on the
-            BatchNorm-calibrated checkpoint at config A's and config B's sizes - the north-star 1e-4 with a 6x margin
-            (tests/test_pair_gpu.py gates it literally) - at about 3/4 of the fp16 throughput.
-            DIRTORCH_AMD_PAIR_STAGES=2..4 (read when the engine is built) extends the paired region.
+      fp16p (default) fp16 with a PAIRED head: where a conditioned network makes most of its 16-bit rounding error
+            (tests/precision_decomposition.py: the image, the stem and layer1, ~94 %) values are kept as pairs of fp16
+            (hi + lo, ~22 bits; two or three MFMAs per product term) - the image, the stem's weights and output and the
+            weights of layer1's 1x1 convs (lo planes that ride in registers of the HBM-bound seam kernels: conv_c3c1.hip,
+            conv_pair.hip); everything else is the fp16 engine.  3.0e-5 / 4.2e-5 of descriptor cosine on the
+            BatchNorm-calibrated checkpoint at config B's / config A's sizes - the north-star 1e-4 with a 2.4-3.3x margin
+            (tests/test_pair_gpu.py gates it literally) - at ~94 % of the fp16 throughput.
+            DIRTORCH_AMD_PAIR_ACTS=1 (read when the engine is built; always on for BasicBlock nets) also keeps layer1's
+            3x3 weights and the tensors inside its blocks as pairs: 1.5e-5 / 1.7e-5 at ~83 % of the fp16 throughput.
+            DIRTORCH_AMD_PAIR_STAGES=2..4 extends the paired region beyond layer1.
       fp16  11-bit mantissa everywhere at the full 16-bit MFMA rate.  Meets the 1e-4 gate on the synthetic checkpoints
             with a 10-1000x margin but sits AT it (0.9e-4 ... 1.3e-4) on the calibrated one (tests/test_scale_gpu.py).
             Both fp16 modes saturate at 65504: the engine's overflow word turns that into an error in the extraction

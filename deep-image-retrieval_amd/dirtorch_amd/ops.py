@@ -135,6 +135,33 @@ def conv_c3c1_ds(t2, x, wcat, bias, w1, bias1, relu3=True, relu1=True):
     return y, t1
 
 
+def conv_c3c1_wpair(t2, w3, bias3, res, w1, bias1, relu3=True, relu1=True):
+    """The fused seam with paired weights (dir_conv_c3c1_wpair, fp16, planes 64): w3 = (hi, lo) [256, 64], w1 = (hi, lo)
+    or (hi, None) [P2, 256]; t2 [B,H,W,64], res [B,H,W,256] single fp16 planes -> (y [B,H,W,256], t1 [B,H,W,P2])."""
+    (w3h, w3l), (w1h, w1l) = w3, w1
+    _need_cuda(t2, w3h, w3l, bias3, res, w1h, bias1)
+    B, H, W, P = t2.shape
+    P2 = w1h.shape[0]
+    y = torch.empty(B, H, W, 4 * P, dtype=t2.dtype, device=t2.device)
+    t1 = torch.empty(B, H, W, P2, dtype=t2.dtype, device=t2.device)
+    call('dir_conv_c3c1_wpair', ptr(t2), ptr(w3h), ptr(w3l), ptr(bias3), ptr(res), ptr(y), ptr(w1h),
+         ptr(w1l) if w1l is not None else None, ptr(bias1), ptr(t1), B, H, W, P2, int(bool(relu3)), int(bool(relu1)), stream_ptr())
+    return y, t1
+
+
+def conv_c3c1_ds_wpair(t2, x, wcat, bias, w1, bias1, relu3=True, relu1=True):
+    """... and its downsample form (dir_conv_c3c1_ds_wpair): x = (hi, lo) [B,H,W,64] the paired block input,
+    wcat = (hi, lo) [256, 128] = [w3 | wds], w1 = (hi, lo) [64, 256] -> (y [B,H,W,256], t1 [B,H,W,64])."""
+    (xh, xl), (wh, wl), (w1h, w1l) = x, wcat, w1
+    _need_cuda(t2, xh, xl, wh, wl, bias, w1h, w1l, bias1)
+    B, H, W, P = t2.shape
+    y = torch.empty(B, H, W, 256, dtype=t2.dtype, device=t2.device)
+    t1 = torch.empty(B, H, W, 64, dtype=t2.dtype, device=t2.device)
+    call('dir_conv_c3c1_ds_wpair', ptr(t2), ptr(xh), ptr(xl), ptr(wh), ptr(wl), ptr(bias), ptr(y), ptr(w1h), ptr(w1l),
+         ptr(bias1), ptr(t1), B, H, W, int(bool(relu3)), int(bool(relu1)), stream_ptr())
+    return y, t1
+
+
 def conv_dual(t2, x, wcat, bias, stride2=2, relu=True):
     """conv3 + downsample as one two-source GEMM (dir_conv_dual): t2 [B,OH,OW,Cin], x [B,H2,W2,Cin2],
     wcat [Cout, Cin + Cin2], bias fp32 [Cout] -> y [B,OH,OW,Cout]."""

@@ -241,6 +241,18 @@ int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* 
 int dir_conv_c3c1_ds(const void* t2, const void* x, const void* wcat, const float* bias, void* y, const void* w1,
                      const float* bias1, void* t1, int B, int H, int W, int relu3, int relu1, int dtype,
                      void* stream);
+/* Both seams with PAIRED WEIGHTS (DIR_FP16P, fp16 only; csrc/conv_c3c1.hip WP3 / WP1): every weight matrix comes as two
+ * fp16 planes, value = hi + lo with lo = fp16(w - hi) (~22 bits), and every product term costs two MFMAs instead of one -
+ * free on these HBM-bound kernels.  Activations are single fp16 planes, except the block input x of the DS form (the
+ * stem's pooled output), which is a pair as well: [w3 | wds] . [t2 ; x_hi + x_lo] with the lo x lo term dropped.
+ * P = 64 (layer1: dirtorch/nets/backbones/resnet.py:67-87, 134-141); P2 = 64 needs w1_lo, P2 = 128 (the layer1 ->
+ * layer2 boundary, whose conv1 belongs to layer2) takes w1_lo = NULL for single-plane weights there. */
+int dir_conv_c3c1_wpair(const void* t2, const void* w3, const void* w3_lo, const float* bias3, const void* res, void* y,
+                        const void* w1, const void* w1_lo, const float* bias1, void* t1, int B, int H, int W, int P2,
+                        int relu3, int relu1, void* stream);
+int dir_conv_c3c1_ds_wpair(const void* t2, const void* x, const void* x_lo, const void* wcat, const void* wcat_lo,
+                           const float* bias, void* y, const void* w1, const void* w1_lo, const float* bias1, void* t1,
+                           int B, int H, int W, int relu3, int relu1, void* stream);
 /* Slow, obviously-correct direct convolution with the same contract (device-side checker). */
 int dir_conv_bn_act_naive(const void* x, const void* w, const float* bias, const void* res,
                           void* y, int B, int H, int W, int Cin, int Cout, int R, int S,

@@ -50,7 +50,7 @@ from synth import (ARCH, BN_EPS, conv_specs, synth_state_dict, synth_images,  # 
 def _q(t, quant):
     if quant is None:
         return t
-    if quant == 'fp16p' or isinstance(quant, tuple):   # outside the paired head DIR_FP16P is fp16
+    if quant in ('fp16p', 'fp16pa') or isinstance(quant, tuple):   # outside the paired head DIR_FP16P is fp16
         quant = 'fp16'
     if quant == 'pair':   # the paired head of DIR_FP16P (csrc/conv_pair.hip): v ~ fp16(v) + fp16(v - fp16(v))
         hi = t.to(torch.float16).to(torch.float32)
@@ -82,35 +82,41 @@ def resnet_features(sd, arch, x, quant=None, with_x4=False):
     """ResNet.forward up to layer4 (fc_out == 0 for *_rmac): [B,3,H,W] -> [B,C,h,w] fp32.
     with_x4 = the out_layer == -1 form (resnet.py:166-167): returns (layer3 map, layer4 map)."""
     bottleneck, layers = ARCH[arch]
-    # quant = 'fp16p' (DIR_FP16P): the image, the stem and - inside the first `pair_stages` stages - the weights and the
-    # tensors between a bottleneck's convs (t1, t2, the downsample branch) are fp16 PAIRS (~22 bits); every block OUTPUT
-    # (the 4P-wide residual carry) is a single fp16 plane, and the rest of the trunk is 'fp16'
-    fp16p = quant == 'fp16p' or (isinstance(quant, tuple) and quant[0] == 'fp16p')
+    # quant = 'fp16p' (DIR_FP16P): the image, the stem (weights and output) and - inside the first `pair_stages` stages -
+    # the weights of the 1x1 convs are fp16 PAIRS (~22 bits); everything else is 'fp16'.
+    # quant = 'fp16pa' (DIRTORCH_AMD_PAIR_ACTS=1; what BasicBlock nets always get, their layer1 has no 1x1): there ALL
+    # weights and the tensors between a block's convs (t1, t2, the downsample branch) are pairs as well.  Every block
+    # OUTPUT (the 4P-wide residual carry) is a single fp16 plane in both.  ('fp16p' | 'fp16pa', pair_stages) moves the boundary.
+    name = quant[0] if isinstance(quant, tuple) else quant
+    fp16p = name in ('fp16p', 'fp16pa')
+    acts = fp16p and (name == 'fp16pa' or not bottleneck)
     pair_stages = (quant[1] if isinstance(quant, tuple) else 1) if fp16p else 0
     tail_quant = 'fp16' if fp16p else quant
     quant = 'pair' if fp16p else quant
     x = _q(x.float(), quant)
     x = _q(F.relu(_conv_bn(sd, x, 'conv1.weight', 'bn1', 2, 3, quant)), quant)
+    qa = quant if (not fp16p or acts) else 'fp16'     # tensors inside a block
+    q3 = qa                                            # weights of the 3x3 convs
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     inplanes = 64
     exp = 4 if bottleneck else 1
     for s, planes in enumerate((64, 128, 256, 512)):
         for j in range(layers[s]):
             if fp16p and s >= pair_stages:
-                quant = tail_quant
+                quant = qa = q3 = tail_quant
             pre = 'layer%d.%d' % (s + 1, j)
             stride = 2 if (j == 0 and s > 0) else 1
             residual = x
             if bottleneck:
-                out = _q(F.relu(_conv_bn(sd, x, pre + '.conv1.weight', pre + '.bn1', 1, 0, quant)), quant)
-                out = _q(F.relu(_conv_bn(sd, out, pre + '.conv2.weight', pre + '.bn2', stride, 1, quant)), quant)
+                out = _q(F.relu(_conv_bn(sd, x, pre + '.conv1.weight', pre + '.bn1', 1, 0, quant)), qa)
+                out = _q(F.relu(_conv_bn(sd, out, pre + '.conv2.weight', pre + '.bn2', stride, 1, q3)), qa)
                 out = _conv_bn(sd, out, pre + '.conv3.weight', pre + '.bn3', 1, 0, quant)
             else:
-                out = _q(F.relu(_conv_bn(sd, x, pre + '.conv1.weight', pre + '.bn1', stride, 1, quant)), quant)
-                out = _conv_bn(sd, out, pre + '.conv2.weight', pre + '.bn2', 1, 1, quant)
+                out = _q(F.relu(_conv_bn(sd, x, pre + '.conv1.weight', pre + '.bn1', stride, 1, q3)), qa)
+                out = _conv_bn(sd, out, pre + '.conv2.weight', pre + '.bn2', 1, 1, q3)
             if j == 0 and (stride != 1 or inplanes != planes * exp):
                 residual = _q(_conv_bn(sd, x, pre + '.downsample.0.weight', pre + '.downsample.1',
-                                       stride, 0, quant), quant)
+                                       stride, 0, quant), qa)
             x = _q(F.relu(out + residual), tail_quant)     # block outputs: one plane in every mode
             inplanes = planes * exp
         if s == 2:

@@ -64,9 +64,10 @@ def short(name):
     m = re.search(r'conv_f32_kernel<(\d+)>', name)
     if m:   # the strict fp32 path (csrc/conv_f32.hip)
         return 'conv_f32<128x%s>' % m.group(1)
-    m = re.search(r'conv_c3c1_kernel<dir::(\w+), (\d+), (\w+), (\d+)>', name)
-    if m:
-        return 'conv_c3c1<%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv_c3c1_kernel<dir::(\w+), (\d+), (\w+), (\d+)(?:, (\w+), (\w+))?>', name)
+    if m:   # <DT, P, DS, P2[, WP3, WP1]>: wp = paired weights (DIR_FP16P)
+        return 'conv_c3c1<%s%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '',
+                                          ',wp' if m.group(5) == 'true' else '', m.group(1).lower())
     m = re.search(r'conv_seam3_kernel<dir::(\w+)>', name)
     if m:   # the layer3 seam (csrc/conv_seam3.hip), opt-in
         return 'conv_seam3<256>[%s]' % m.group(1).lower()
@@ -76,9 +77,10 @@ def short(name):
     m = re.search(r'conv1x1_ring_kernel<dir::(\w+)>', name)
     if m:
         return 'conv_igemm<128x256_ring1x1>[%s]' % m.group(1).lower()
-    m = re.search(r'conv1x1_persist_kernel<dir::(\w+)(?:, (\w+), (\w+))?>', name)
-    if m:
-        return 'conv_igemm<256x256_persist1x1%s>[%s]' % ('_x3' if m.group(2) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv1x1_persist_kernel<dir::(\w+)(?:, (\w+), (\w+))?(?:, (\w+))?>', name)
+    if m:   # <DT, XDEEP, RES[, DUAL]>
+        return 'conv_igemm<256x256_persist1x1%s%s>[%s]' % ('_x3' if m.group(2) == 'true' else '',
+                                                           '/dual' if m.group(4) == 'true' else '', m.group(1).lower())
     m = re.search(r'conv_patch3x3s_kernel<dir::(\w+), (\d+)>', name)
     if m:
         return 'conv_igemm<256x256_patch3x3s>[%s]' % m.group(1).lower()

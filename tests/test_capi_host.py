@@ -184,7 +184,7 @@ def test_profile_tooling_knows_every_engine_kernel():
         k = S.bench_kernel_name(S.short(n))
         if 'conv' in n and 'finalize' not in n and 'naive' not in n:
             m = re.match(r'^conv_igemm<([^>/]+)(/splitk|/dual)?>$', k)
-            assert (m and m.group(1) in variants) or re.match(r'^conv_c3c1<(64|128)(,ds)?>$', k) or k == 'conv_seam3<256>' or \
+            assert (m and m.group(1) in variants) or re.match(r'^conv_c3c1<(64|128)(,ds)?(,wp)?>$', k) or k == 'conv_seam3<256>' or \
                 re.match(r'^conv_f32<128x(64|128)>$', k) or re.match(r'^conv_pair<128x(64|128)_(patch3x3_)?x?w(/dual)?>$', k), (n, k)
         else:
             assert k in forward or k in other, (n, k)
