@@ -540,8 +540,7 @@ int dir_conv_dual(const void* t2, const void* x, const void* wcat, const float* 
         return fail(DIR_ERR_INVALID, "conv_dual: tensor exceeds 2^31 bytes; lower the batch");
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "conv_dual: bad dtype");
     // (small shapes included: the op-level entry point runs the form wherever the tile divides Cout)
-    // what the engine runs at batch size: the persistent two-source ring (conv_persist.hip), or conv_igemm.hip's tile under
-    // DIRTORCH_AMD_DUAL_IGEMM=1
+    // what the engine runs at batch size: the persistent two-source ring (conv_persist.hip DUAL)
     const int variant = conv_pick_dual_variant(a, true);
     if (variant < 0) return fail(DIR_ERR_INVALID, "conv_dual: Cout must be a multiple of 256");
     return conv_launch(a, dtype, variant, (hipStream_t)stream);

@@ -51,12 +51,9 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shr) {
 
 // SPLITK instantiations (a few small-tile variants) carry the split-K bookkeeping; the others compile
 // exactly as if it did not exist - its extra scalar state costs 8-70 VGPRs in the big tiles.
-// DUAL instantiations (two variants) take the K dimension from TWO tensors: K-steps [0, Cin/BK) from x (a flat
-// 1x1 stride-1 source: the conv3 of a bottleneck), the rest from x2 through its own descriptor and a
-// strided pixel map (the block's 1x1 downsample branch, resnet.py:134-141), against weights concatenated
-// along K.  relu([W3 | Wds] . [t2 ; x_s] + b3 + bds) is the whole tail of a stage's first block: the
-// Cout-wide residual tensor is neither written nor read, and the downsample launch disappears.
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK, bool DUAL = false>
+// (The two-source form of rounds 2-3 - conv3 + the block's 1x1 downsample as one GEMM over [t2 ; x_s], one tile per
+// workgroup - lives on the persistent ring since round 4: conv_persist.hip DUAL, bit-identical, 5-13 % faster.)
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvArgs a) {
     static_assert(NST >= 2 && NST <= 4, "ring depth");
     static_assert((BK == 64 || BK == 32) && (!CIN16 || BK == 64), "K-step");
@@ -152,34 +149,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
         const int row = i * (NT / CPR) + tid / CPR;
         wvoff[i] = (uint32_t)(((tile_n * BN + row) * a.Ktot + srcchunk * 8) * 2);
     }
-    // DUAL: the second source's per-lane offsets (output pixel -> strided pixel of x2) and descriptor
-    const __amdgpu_buffer_rsrc_t rsrc_x2 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : a.x_bytes, 0x00020000);
-    uint32_t xvoff2[DUAL ? NA : 1];
-    const int T1 = DUAL ? a.Cin / BK : 0;      // K-steps served by the first source
-    if (DUAL) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = i * (NT / CPR) + tid / CPR;
-            const int m = tile_m * BM + row;
-            const uint32_t mm = m < a.M ? (uint32_t)m : 0u;
-            const uint32_t b = fast_div(mm, a.div_ohw_mul, a.div_ohw_shr);
-            const uint32_t rem = mm - b * (uint32_t)(a.OH * a.OW);
-            const uint32_t oh = fast_div(rem, a.div_ow_mul, a.div_ow_shr);
-            const uint32_t ow = rem - oh * (uint32_t)a.OW;
-            const uint32_t off = (((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.Cin2 + srcchunk * 8) * 2;
-            xvoff2[DUAL ? i : 0] = m < a.M ? off : kOOB;
-        }
-    }
-
     // K-step t: filter tap `tap` (stem: filter row), byte offset `koff` of that tap/channel slice
     auto issue = [&](int t, int tap, int koff, char* stage) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             char* dst = stage + (i * NT + wave * 64) * 16;
-            if (DUAL && t >= T1) {
-                dma16(rsrc_x2, dst, xvoff2[DUAL ? i : 0], (t - T1) * RB);
-            } else if (one_tap) {
+            if (one_tap) {
                 dma16(rsrc_x, dst, xvoff[i], koff);
             } else {
                 const uint32_t v = ((xmask[i] >> tap) & 1u) ? (uint32_t)(xbase[i] + koff) : kOOB;
@@ -412,7 +387,7 @@ static void fastdiv_init(uint32_t d, uint32_t& mul, uint32_t& shr) {
     shr = p - 32;
 }
 
-template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK = false, bool DUAL = false>
+template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK = false>
 static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int TN = BN / WGN / 32;
@@ -421,7 +396,7 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     constexpr int EPI_BYTES = (NT / 64) * 32 * EROW;
     constexpr int LDS = (NST * STAGE_BYTES > EPI_BYTES) ? NST * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK, DUAL>;
+    auto kern = conv_igemm_kernel<DT, BM, BN, WGM, WGN, NST, BK, CIN16, SPLITK>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -431,7 +406,6 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW);
-    if (DUAL) b.x2_bytes = (uint32_t)((size_t)a.B * a.H2 * a.W2 * a.Cin2 * 2);
     fastdiv_init((uint32_t)(a.OH * a.OW), b.div_ohw_mul, b.div_ohw_shr);
     fastdiv_init((uint32_t)a.OW, b.div_ow_mul, b.div_ow_shr);
     // a short K loop never touches the far slots of the ring: ask for less LDS, more residency
@@ -447,14 +421,6 @@ static hipError_t launch_variant(const ConvArgs& a, hipStream_t stream) {
      {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
       launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
      {nullptr, nullptr}, 0, {nullptr, nullptr}, {nullptr, nullptr}}
-// ... plus the two-source K instantiation (conv3 + downsample of a stage's first block)
-#define DIR_VARIANT_DUAL(BM, BN, WGM, WGN, NST, BK, NAME)                                    \
-    {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
-     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false>,                                \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false>},                               \
-     {nullptr, nullptr}, 0, {nullptr, nullptr},                                              \
-     {launch_variant<BF16, BM, BN, WGM, WGN, NST, BK, false, false, true>,                   \
-      launch_variant<FP16, BM, BN, WGM, WGN, NST, BK, false, false, true>}}
 // ... plus the split-K instantiation (small-M layers)
 #define DIR_VARIANT_SK(BM, BN, WGM, WGN, NST, BK, NAME)                                      \
     {NAME, BM, BN, 64 * WGM * WGN, NST, BK,                                                  \
@@ -478,7 +444,7 @@ static const ConvVariant kVariants[] = {
     DIR_VARIANT16(256, 64, 4, 1, 2, "256x64_w4x1"),
     DIR_VARIANT(256, 128, 4, 2, 2, 64, "256x128_w4x2"),
     DIR_VARIANT(128, 256, 2, 4, 2, 64, "128x256_w2x4"),
-    DIR_VARIANT_DUAL(256, 256, 4, 2, 2, 64, "256x256_w4x2"),
+    DIR_VARIANT(256, 256, 4, 2, 2, 64, "256x256_w4x2"),
     DIR_VARIANT_SK(64, 128, 2, 2, 2, 64, "64x128_w2x2"),
     DIR_VARIANT16(64, 64, 2, 1, 2, "64x64_w2x1"),
     DIR_VARIANT(64, 128, 2, 2, 4, 64, "64x128_w2x2_s4"),
@@ -643,25 +609,18 @@ int conv_pick_variant(const ConvArgs& a) {
     return last;
 }
 
-// Two-source form: which of the DUAL instantiations runs a given conv3 + downsample pair.
+// Two-source form (conv3 + downsample of the first block of layers 2-4): the one kernel that carries it.
+// History: conv_igemm.hip's own 256x256 tile (rounds 2-3: 0.359 / 0.261 / 0.206 ms on the first blocks of layers 2 / 3 / 4 where the
+// persistent ring takes 0.311 / 0.238 / 0.197, bit-identical), a 3-slot 128x256 tile (0.39 / 0.29 / 0.22) and a split loader /
+// consumer ring (0.357 / 0.267 / 0.224) were measured and retired.
 int conv_pick_dual_variant(const ConvArgs& a, bool any_size) {
     const bool ok = a.x2 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
                     a.Cin % 64 == 0 && a.Cin2 % 64 == 0 && a.res == nullptr && a.ksplit <= 1;
     if (!ok) return -1;
-    // one instantiation carries the form: 256x256, 8 waves (the two-workgroups-per-CU k32 tile goes over
-    // 128 VGPRs with the second source's offsets and loses its occupancy)
-    // (a two-source instantiation of the 3-slot 128x256 tile, two stages in flight, measured 0.39 / 0.29 / 0.22 ms
-    // against 0.31 / 0.24 / 0.19 ms on the first blocks of layers 2 / 3 / 4 - gpurun_out/r3i - and was removed)
-    // (a two-source form of the split loader / consumer ring, conv_ring.hip, was measured in round 3 - bit-identical,
-    // 0.357 / 0.267 / 0.224 ms against 0.342 / 0.254 / 0.215 ms for this one-role tile: four consumer waves multiply slower
-    // than eight and these GEMMs are not memory-bound enough for the overlap to pay - and retired in round 4)
     // (any_size: the op-level entry point runs the form on small shapes too - the tests')
     if (a.Cout % 256 != 0 || (!any_size && (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192)) return -1;
-    // round 4: the persistent deep-X ring with a second pixel source (conv_persist.hip DUAL); DIRTORCH_AMD_DUAL_IGEMM=1
-    // restores the one-tile-per-workgroup tile (A/B and bisecting; read per call: the tests flip it)
-    const bool igemm_dual = getenv("DIRTORCH_AMD_DUAL_IGEMM") != nullptr;
-    const int v = find_variant(igemm_dual ? "256x256_w4x2" : "256x256_persist1x1_x3");
-    if (v < 0 || kVariants[v].launch_dual[0] == nullptr || a.Cout % kVariants[v].BN != 0) return -1;
+    const int v = find_variant("256x256_persist1x1_x3");
+    if (v < 0 || kVariants[v].launch_dual[0] == nullptr) return -1;
     return v;
 }
 

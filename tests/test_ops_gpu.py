@@ -691,19 +691,16 @@ DUAL_SHAPES = [(2, 13, 11, 128, 512, 256, 2), (1, 9, 17, 256, 1024, 512, 2), (1,
                (3, 20, 20, 64, 256, 64, 1)]
 
 
-@pytest.mark.parametrize('form', ['persistent', 'igemm'])
 @pytest.mark.parametrize('dname', ['bf16', 'fp16'])
 @pytest.mark.parametrize('B,OH,OW,Cin,Cout,Cin2,s2', DUAL_SHAPES + [(2, 64, 64, 128, 512, 256, 2), (3, 33, 47, 256, 1024, 512, 2),
                                                       (4, 96, 128, 128, 512, 256, 2)])
-def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2, s2, dname, form, monkeypatch):
+def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2, s2, dname):
     """dir_conv_dual: relu(conv1x1(t2; w3) + b3 + conv1x1_stride(x; wds) + bds) as one GEMM whose K runs over
     two tensors, against the fp32 CPU oracle of the two convolutions on the same rounded operands (odd input
-    sizes: the strided pixel map, ragged last tile).  Both forms: the persistent deep-X ring with a second pixel source
-    (conv_persist.hip DUAL, the default since round 4; the last shape gives every workgroup more than one tile) and
-    conv_igemm.hip's one-tile-per-workgroup tile (DIRTORCH_AMD_DUAL_IGEMM=1) - same K order, bit-identical.
-    (Round 3 also carried a split loader / consumer form in conv_ring.hip - 4-5 % slower - retired in round 4.)"""
-    if form == 'igemm':
-        monkeypatch.setenv('DIRTORCH_AMD_DUAL_IGEMM', '1')
+    sizes: the strided pixel map, ragged last tile).  The kernel: the persistent deep-X ring with a second pixel source
+    (conv_persist.hip DUAL; the last shape gives every workgroup more than one tile).  Rounds 2-3 ran the same GEMM one
+    tile per workgroup in conv_igemm.hip (bit-identical, 5-13 % slower) and round 3 a split loader / consumer form in
+    conv_ring.hip (4-5 % slower still): both retired in round 4."""
     ops = _ops()
     dt = DTYPES[dname]
     H2, W2 = (OH - 1) * s2 + 1 + (s2 - 1), (OW - 1) * s2 + 1      # odd / even input sizes that map to OH x OW
@@ -720,9 +717,6 @@ def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2
     ref = F.relu(conv_reference(t2, w3, b3, None, 1, 0, False) + ds)
     check_close(y, ref, dname, 'two-source conv3 + downsample')
     assert torch.equal(y, ops.conv_dual(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), stride2=s2, relu=True))
-    if form == 'persistent':      # the other form accumulates the same K-steps in the same order
-        monkeypatch.setenv('DIRTORCH_AMD_DUAL_IGEMM', '1')
-        assert torch.equal(y, ops.conv_dual(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), stride2=s2, relu=True))
 
 
 def test_fused_seam_argument_errors():

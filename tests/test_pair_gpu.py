@@ -334,7 +334,9 @@ def test_north_star_tolerance_as_stated_fp16p(arch, B, H, W, CB, form, monkeypat
     assert errs['fp16p'] < 1e-4, errs            # the stated gate, no allowance
     # ... with the margin the design promises (emulation: 4.2e-5 / 3.0e-5 for 'weights', 1.7e-5 / 1.3e-5 for 'acts')
     assert errs['fp16p'] < (6e-5 if form == 'weights' else 4e-5), errs
-    assert e_ge < 3e-5, e_ge                     # an implementation OF the emulated arithmetic (fp16 tail roundings differ)
+    # an implementation OF the emulated arithmetic: what separates the two is independent fp16 roundings of the same
+    # tensors (summation order) - measured 2.3e-5 / 2.8e-5 with single-plane activations in layer1, 8.6e-6 / 8.4e-6 with pairs
+    assert e_ge < (5e-5 if form == 'weights' else 3e-5), e_ge
 
 
 def test_fp16p_plumbing(monkeypatch):
