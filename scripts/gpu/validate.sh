@@ -29,7 +29,7 @@ if [ -z "$SKIP_PROF" ]; then
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/$O/prof_write -o bench -- python $R/bench.py $SHORT > /dev/null 2> $R/$O/prof_write.err)
   python scripts/summarize_prof.py stats $O/prof_stats $O/kernel_stats.txt | head -24
   python scripts/summarize_prof.py table $O/launches.json $O/prof_stats $O/prof_sq $O/prof_fetch $O/prof_write $O/kernel_roofline.txt $O/traffic.json | cut -c1-200 | head -60
-  tail -2 $O/prof_sq.err $O/prof_fetch.err
+  tail -n 2 $O/prof_sq.err $O/prof_fetch.err
   find $O -name '*.csv' -size +4M -delete
   du -sh $O
 fi
