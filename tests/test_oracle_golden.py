@@ -107,6 +107,28 @@ def test_quant_emulation_is_close():
         assert np.all(1 - O.cosine(got, ref) < tol), (q, 1 - O.cosine(got, ref))
 
 
+def test_paired_head_emulations_are_ordered_by_what_they_pair():
+    """The storage points of DIR_FP16P's two forms (oracle quant='fp16p': image, stem and layer1's 1x1 weights as fp16
+    pairs; 'fp16pa': layer1's 3x3 weights and inner tensors too), on a BatchNorm-calibrated ResNet-50: each is closer to
+    fp32 than the one before it, a BasicBlock net has no 1x1 in layer1 so both names mean the same thing there, and the
+    pair representation itself holds ~22 bits."""
+    import torch
+    sd = O.calibrated_state_dict('resnet50', O.synth_images(99, 8, 96, 96), seed=7)
+    x = O.synth_images(5, 4, 96, 96)
+    ref = O.rmac_forward(sd, 'resnet50', x).numpy()
+    err = {q if isinstance(q, str) else '%s/%d' % q: float((1 - O.cosine(O.rmac_forward(sd, 'resnet50', x, quant=q).numpy(), ref)).max())
+           for q in ('fp16', 'fp16p', 'fp16pa', ('fp16pa', 2))}
+    assert err['fp16pa/2'] < err['fp16pa'] < err['fp16p'] < err['fp16'], err
+    sd18 = O.calibrated_state_dict('resnet18', O.synth_images(99, 8, 96, 96), seed=7)
+    a = O.rmac_forward(sd18, 'resnet18', x, quant='fp16p')
+    b = O.rmac_forward(sd18, 'resnet18', x, quant='fp16pa')
+    assert torch.equal(a, b)
+    v = torch.randn(4096, generator=torch.Generator().manual_seed(1)) * 3
+    v = torch.where(v.abs() < 0.25, torch.full_like(v, 0.7), v)       # (tiny values: the lo plane goes subnormal)
+    assert float(((O._q(v, 'pair') - v).abs() / v.abs()).max()) < 2.0 ** -21
+    assert float(((O._q(v, 'fp16') - v).abs() / v.abs()).max()) > 2.0 ** -13
+
+
 RESIZE_CASES = [(37, 53, 52, 75), (64, 64, 45, 45), (120, 90, 170, 127), (100, 100, 100, 141),
                 (50, 70, 50, 35), (33, 47, 11, 13), (200, 300, 71, 424), (17, 19, 68, 76), (10, 10, 1, 1),
                 (5, 7, 500, 3), (96, 128, 96, 128), (240, 320, 339, 452), (240, 320, 170, 226)]
