@@ -224,7 +224,7 @@ def other_workloads(args, x_bench):
             if name == 'distractors':
                 out[name] = {'db_rows': a.db_rows, 'queries': a.queries, 'ms_per_step': r['ms_per_step'],
                              'db_rows_per_sec': r['value'], 'sim_ms': r['roofline']['avg_launch_ms'],
-                             'sim_hbm_frac': r['roofline']['frac'], 'rank_ap_ms': r['roofline']['rank_ap_ms'],
+                             'sim_hbm_frac': r['roofline']['frac'], 'sim_kernel': r['roofline']['kernel'], 'rank_ap_ms': r['roofline']['rank_ap_ms'],
                              'mAP_medium': r['config']['mAP_medium']}
             else:
                 out[name] = {'images_per_sec_3scale': r['value'], 'ms_per_step': r['ms_per_step'], 'batch': a.ms_batch,
@@ -319,6 +319,10 @@ def bench_distractors(args, world, rank, dist):
         db.hard.append(sorted(idx[80:160].tolist()))
         db.junk.append(sorted(idx[160:].tolist()))
     tables = ranking.build_probe_tables(db)
+    # L2-normalised descriptors: the fp16-pair form of the large-database similarity (csrc/sim_split.hip PAIR) applies; the
+    # range is established ONCE per database, outside the timed steps, the way a retrieval service would (ranking.is_unit_range)
+    unit = not args.sim_general and ranking.is_unit_range(qs, local)
+    sim = lambda q, b: ops.similarity(q, b, unit_range=unit)   # noqa: E731
     full = torch.empty(world * rows, D, device='cuda') if args.exchange == 'descriptors' and world > 1 else None
     sc_all = torch.empty(world, Q, rows, device='cuda') if args.exchange == 'scores' and world > 1 else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -334,9 +338,9 @@ def bench_distractors(args, world, rank, dist):
                 ev[1].record()
             # (shards of unequal length - 1 006 322 % 8 = 2 - arrive padded and are scored block by block:
             # dirtorch_amd.distributed.score_gathered, tests/test_ranking_gpu.py::test_sharded_scoring_*)
-            scores = ddist.score_gathered(qs, full, N, world, ops.similarity) if world > 1 else ops.similarity(qs, local[:N])
+            scores = ddist.score_gathered(qs, full, N, world, sim) if world > 1 else sim(qs, local[:N])
         else:
-            mine = ops.similarity(qs, local)                          # [Q, rows] (padding rows score 0)
+            mine = sim(qs, local)                                     # [Q, rows] (padding rows score 0)
             if record:
                 ev[1].record()
             if world > 1:
@@ -396,7 +400,8 @@ def bench_distractors(args, world, rank, dist):
                                % (N, Q, 'descriptor blocks' if args.exchange == 'descriptors' else 'score blocks'),
                    'rccl_ranks': dist.get_world_size() if dist is not None else 0,
                    'exchange': args.exchange, 'rows_per_rank': rows, 'mAP_medium': round(float(np.mean([a['medium'] for a in aps])), 6)},
-        'roofline': {'bound': 'hbm', 'kernel': ('sim_split_kernel' if os.environ.get('DIRTORCH_AMD_SIM_V1') else 'sim_split_lc_kernel') if sim_rows >= 32768 else 'gemm_nt_f32',
+        'roofline': {'bound': 'hbm', 'kernel': ('sim_split_kernel' if os.environ.get('DIRTORCH_AMD_SIM_V1') else
+                                                ('sim_split_lc_kernel<pair: two fp16 planes>' if unit else 'sim_split_lc_kernel')) if sim_rows >= 32768 else 'gemm_nt_f32',
                      'achieved': round(sim_bytes / (sim_ms * 1e-3) / 1e9, 1) if sim_ms else None, 'peak': PEAK_HBM_GBS,
                      'unit': 'GB/s', 'frac': round(sim_bytes / (sim_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sim_ms else None,
                      'traffic': None, 'avg_launch_ms': round(sim_ms, 4), 'algorithmic_bytes_per_launch': sim_bytes,
@@ -520,6 +525,8 @@ def main():
     ap.add_argument('--ms-size', type=int, default=1200, help='multiscale: side of the (square) source images')
     ap.add_argument('--db-rows', type=int, default=1006322, help='distractors: database size (RParis6K + 1M)')
     ap.add_argument('--queries', type=int, default=70)
+    ap.add_argument('--sim-general', action='store_true',
+                    help='distractors: the six-product bf16 similarity kernel (any fp32 operands) instead of the fp16-pair one')
     ap.add_argument('--exchange', default='descriptors', choices=['descriptors', 'scores'],
                     help="distractors: what crosses xGMI - the [N/W, 2048] descriptor blocks (north_star) or, the "
                          "cheaper layout, each rank's [Q, N/W] score block")

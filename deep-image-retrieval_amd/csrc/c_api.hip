@@ -663,21 +663,22 @@ int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const flo
     DIR_CATCH
 }
 
-int dir_similarity(const float* queries, int Q, const float* database, int N, int D, float* scores,
-                   void* stream) {
-    DIR_TRY
+static int similarity_impl(const float* queries, int Q, const float* database, int N, int D, float* scores, void* stream,
+                           bool unit_range) {
     if (Q < 0 || N < 0 || D <= 0) return fail(DIR_ERR_INVALID, "similarity: bad size");
     if (Q == 0 || N == 0) return DIR_OK;
     if (!queries || !database || !scores) return fail(DIR_ERR_INVALID, "similarity: null pointer");
     // Large databases (the 10^6-distractor protocol): three-plane bf16 split on the matrix cores, fp32-accurate
-    // products, ~2x the speed of the exact fp32 MFMA chain (sim_split.hip).  Small ones, odd widths and
+    // products, ~2x the speed of the exact fp32 MFMA chain (sim_split.hip) - or, for operands the caller knows to be
+    // bounded (dir_similarity_unit), two fp16 planes and half the products.  Small ones, odd widths and
     // DIRTORCH_AMD_SIM_EXACT=1 keep the k-ordered fmaf chain of gemm_nt_f32.
     const bool exact = getenv("DIRTORCH_AMD_SIM_EXACT") != nullptr;   // read per call: a ms-scale operation
     if (!exact && N >= kSimSplitMinRows && similarity_split_admissible(database, D, queries, D, N, Q, D)) {
         const size_t bytes = similarity_split_workspace_bytes(Q, D);
         void* ws = nullptr;
         if (hipMallocAsync(&ws, bytes, (hipStream_t)stream) == hipSuccess) {   // stream-ordered: freed after the kernels
-            const int rc = similarity_split(database, D, queries, D, scores, N, N, Q, D, ws, bytes, (hipStream_t)stream);
+            const int rc = similarity_split(database, D, queries, D, scores, N, N, Q, D, ws, bytes, (hipStream_t)stream,
+                                            unit_range);
             const hipError_t fe = hipFreeAsync(ws, (hipStream_t)stream);
             if (rc != DIR_OK) return rc;
             DIR_HIP_CHECK(fe);
@@ -687,6 +688,19 @@ int dir_similarity(const float* queries, int Q, const float* database, int N, in
     }
     return gemm_nt_f32(database, D, queries, D, scores, N, N, Q, D, nullptr, nullptr, nullptr,
                        (hipStream_t)stream);
+}
+
+int dir_similarity(const float* queries, int Q, const float* database, int N, int D, float* scores,
+                   void* stream) {
+    DIR_TRY
+    return similarity_impl(queries, Q, database, N, D, scores, stream, false);
+    DIR_CATCH
+}
+
+int dir_similarity_unit(const float* queries, int Q, const float* database, int N, int D, float* scores,
+                        void* stream) {
+    DIR_TRY
+    return similarity_impl(queries, Q, database, N, D, scores, stream, true);
     DIR_CATCH
 }
 

@@ -43,7 +43,8 @@ int gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out, in
 // large-database similarity on the bf16 matrix cores at fp32 accuracy (sim_split.hip)
 size_t similarity_split_workspace_bytes(int NQ, int K);
 bool similarity_split_admissible(const float* P, int ldp, const float* Q, int ldq, int NP, int NQ, int K);
+// unit_range: operands known to lie in (-64, 64) (L2-normalised descriptors): two fp16 planes instead of three bf16 ones
 int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP, int NQ, int K,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream);
+                     void* workspace, size_t workspace_bytes, hipStream_t stream, bool unit_range = false);
 
 }  // namespace dir

@@ -17,6 +17,15 @@
 // different summation order does (~1e-7 on unit vectors); callers that need the k-ordered fmaf chain keep
 // gemm_nt_f32 (small N, or DIRTORCH_AMD_SIM_EXACT=1).
 //
+// PAIR form (round 4, similarity_split(..., unit_range = true): operands known to lie in (-64, 64) - L2-normalised
+// descriptors): the six bf16 products make the kernel as much matrix-pipe- as HBM-bound (consumers alone 1.64 ms of the
+// 2.0 at config D's sizes).  For bounded operands TWO fp16 planes do the same job:
+//     x * 2^10 = h + l,   h = fp16(.), l = fp16(. - h)          (|l| <= 2^-11 |h|: ~22 bits; exact down to 2^-35 absolute)
+//     x*y ~= (h*h' + (h*l' + l*h')) * 2^-20                     three products; l*l' (2^-22 relative) dropped
+// on v_mfma_f32_32x32x16_f16 - half the MFMAs, two thirds of the query-plane traffic, a shorter split.  fp16 has fp32's
+// precision problem in reverse (5 exponent bits): the 2^10 scale puts unit-vector entries (~2^-6) in the middle of the
+// range, values of magnitude >= 64 overflow h to inf and the scores come out non-finite - loudly wrong, never silently.
+//
 // Work split: one 512-thread workgroup per 256 database rows, one 32-row strip per wave against all 96 query rows
 // (3 accumulator blocks).  The database is used by exactly one wave, so it goes HBM -> LDS as raw fp32 by LDS-DMA
 // (128-byte pieces, XOR-swizzled rows) and is split in registers right before the MFMAs; the query planes are split
@@ -35,6 +44,11 @@ static constexpr int kSlabP = kRowsP * 128;       // 32768
 static constexpr int kStage = kSlabP + kSlabQ;    // 51200
 static constexpr int kStages = 3;
 static constexpr int kLds = kStages * kStage;     // 153600 of 163840
+// PAIR form: two fp16 planes
+static constexpr int kSlabQ2 = 2 * kPlane;        // 12288
+static constexpr int kStage2 = kSlabP + kSlabQ2;  // 45056
+static constexpr int kLds2 = kStages * kStage2;   // 135168
+static constexpr float kPairScale = 1024.f;       // 2^10: |x| < 64 stays finite in fp16, unit-vector entries mid-range
 
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
@@ -52,12 +66,22 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t
     l = BF16::pack(x0, x1);
 }
 
+// x0, x1 (already scaled) -> packed fp16 planes
+__device__ __forceinline__ void split2h(float x0, float x1, uint32_t& h, uint32_t& l) {
+    float a, b;
+    h = FP16::pack(x0, x1);
+    FP16::unpack(h, a, b);
+    l = FP16::pack(x0 - a, x1 - b);
+}
+
 // Query planes as an image of the LDS stages: [query block][K slab of 32][plane h, m, l][96 rows][64 bytes], the
 // four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3.  Rows past NQ and k past K are zero.
+// PAIR: [..][plane h, l (fp16 of 2^10 x)][96 rows][64 bytes]
+template <bool PAIR>
 __global__ void __launch_bounds__(256) split_queries_kernel(const float* __restrict__ Q, int ldq, int NQ, int K,
                                                            uint16_t* __restrict__ img) {
     const int t = blockIdx.x, qb = blockIdx.y, T = gridDim.x;
-    char* dst = (char*)img + ((size_t)qb * T + t) * kSlabQ;
+    char* dst = (char*)img + ((size_t)qb * T + t) * (PAIR ? kSlabQ2 : kSlabQ);
     for (int item = threadIdx.x; item < kQB * 4; item += 256) {
         const int row = item >> 2, pos = item & 3;
         const int chunk = pos ^ ((row >> 2) & 3);
@@ -68,13 +92,16 @@ __global__ void __launch_bounds__(256) split_queries_kernel(const float* __restr
             const int k = t * 32 + chunk * 8 + 2 * e;
             const float x0 = (q < NQ && k < K) ? Q[(size_t)q * ldq + k] : 0.f;
             const float x1 = (q < NQ && k + 1 < K) ? Q[(size_t)q * ldq + k + 1] : 0.f;
-            uint32_t a, b, c;
-            split2(x0, x1, a, b, c);
+            uint32_t a, b, c = 0;
+            if (PAIR)
+                split2h(x0 * kPairScale, x1 * kPairScale, a, b);
+            else
+                split2(x0, x1, a, b, c);
             h[e] = a, m[e] = b, l[e] = c;
         }
         *(u32x4_t*)(dst + 0 * kPlane + row * 64 + pos * 16) = h;
         *(u32x4_t*)(dst + 1 * kPlane + row * 64 + pos * 16) = m;
-        *(u32x4_t*)(dst + 2 * kPlane + row * 64 + pos * 16) = l;
+        if (!PAIR) *(u32x4_t*)(dst + 2 * kPlane + row * 64 + pos * 16) = l;
     }
 }
 
@@ -213,9 +240,12 @@ __global__ void __launch_bounds__(512) sim_split_kernel(const float* __restrict_
 // are the consumers of the old kernel (one 32-row strip each, no memory ops until the final score store), waves 8-11
 // only issue LDS-DMA - 8 database pieces + 4 or 5 KB of the query image per slab each - and wait for it.  One
 // s_barrier per K slab is the hand-off both ways (slab t landed / slot of slab t - 1 is free).
+template <bool PAIR>
 __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restrict__ P, int ldp, int NP, int K,
                                                           const uint16_t* __restrict__ img, float* __restrict__ out,
                                                           int ldo, int NQ, int T) {
+    constexpr int kSlabQ = PAIR ? dir::kSlabQ2 : dir::kSlabQ;     // (shadow the three-plane constants)
+    constexpr int kStage = PAIR ? dir::kStage2 : dir::kStage;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,9 +270,9 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             pvoff[i] = (uint32_t)row * (uint32_t)ldp * 4u + (uint32_t)chunk * 16u;   // rows past `rows`: out of range -> 0
         }
-        // query image of a slab: 18 pieces of 1 KiB; loaders 0 / 1 take 5, loaders 2 / 3 take 4
-        const int q0 = lw < 2 ? lw * 5 : 10 + (lw - 2) * 4;
-        const bool five = lw < 2;
+        // query image of a slab: 18 pieces of 1 KiB; loaders 0 / 1 take 5, loaders 2 / 3 take 4 (PAIR: 12 pieces, 3 each)
+        const int q0 = PAIR ? lw * 3 : (lw < 2 ? lw * 5 : 10 + (lw - 2) * 4);
+        const bool five = !PAIR && lw < 2;
         auto issue = [&](int t) __attribute__((always_inline)) {
             int u = t + rot;
             u = u >= T ? u - T : u;
@@ -251,7 +281,7 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
             for (int i = 0; i < 8; ++i)
                 if (!(DIR_SIM_ABL & 1)) dma16s(rsrc_p, stage + (lw * 8 + i) * 1024, pvoff[i], (uint32_t)u * 128u);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < (PAIR ? 3 : 4); ++i)
                 if (!(DIR_SIM_ABL & 2))
                     dma16s(rsrc_q, stage + kSlabP + (q0 + i) * 1024, (uint32_t)((q0 + i) * 1024 + lane * 16), (uint32_t)u * kSlabQ);
             if (five && !(DIR_SIM_ABL & 2)) dma16s(rsrc_q, stage + kSlabP + (q0 + 4) * 1024, (uint32_t)((q0 + 4) * 1024 + lane * 16), (uint32_t)u * kSlabQ);
@@ -261,7 +291,9 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
         for (int t = 0; t < T; ++t) {
             // this wave's part of slab t has landed; its newest 12 / 13 ops (slab t + 1) may stay in flight
             if (t + 1 < T) {
-                if (five) {
+                if (PAIR) {
+                    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                } else if (five) {
                     asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -300,14 +332,27 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
             for (int j = 0; j < 3; ++j) {
                 ah[j] = *(const u32x4_t*)(stage + aoff + 0 * kPlane + j * 2048 + ach);
                 am[j] = *(const u32x4_t*)(stage + aoff + 1 * kPlane + j * 2048 + ach);
-                al[j] = *(const u32x4_t*)(stage + aoff + 2 * kPlane + j * 2048 + ach);
+                if (!PAIR) al[j] = *(const u32x4_t*)(stage + aoff + 2 * kPlane + j * 2048 + ach);
             }
             u32x4_t bh, bm, bl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                uint32_t h, m, l;
-                split2(e < 2 ? b0[2 * e] : b1[2 * e - 4], e < 2 ? b0[2 * e + 1] : b1[2 * e - 3], h, m, l);
+                uint32_t h, m, l = 0;
+                const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+                if (PAIR)
+                    split2h(x0 * kPairScale, x1 * kPairScale, h, m);
+                else
+                    split2(x0, x1, h, m, l);
                 bh[e] = h, bm[e] = m, bl[e] = l;
+            }
+            if (PAIR) {   // planes (h, m) = (hi, lo) of fp16: leading product + the two corrections
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    lo[j] = FP16::mfma32(__builtin_bit_cast(f16x8_t, am[j]), __builtin_bit_cast(f16x8_t, bh), lo[j]);
+                    lo[j] = FP16::mfma32(__builtin_bit_cast(f16x8_t, ah[j]), __builtin_bit_cast(f16x8_t, bm), lo[j]);
+                    acc[j] = FP16::mfma32(__builtin_bit_cast(f16x8_t, ah[j]), __builtin_bit_cast(f16x8_t, bh), acc[j]);
+                }
+                continue;
             }
 #define DIR_MM(ACC, A, B)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(         \
@@ -332,7 +377,8 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q = qb * kQB + j * 32 + 8 * g + 4 * lhi + e;
-                    if (q < NQ) out[(size_t)q * ldo + n] = acc[j][4 * g + e] + lo[j][4 * g + e];
+                    const float v = acc[j][4 * g + e] + lo[j][4 * g + e];
+                    if (q < NQ) out[(size_t)q * ldo + n] = PAIR ? v * (1.f / (kPairScale * kPairScale)) : v;
                 }
     }
 }
@@ -349,24 +395,32 @@ bool similarity_split_admissible(const float* P, int ldp, const float* Q, int ld
 }
 
 int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP, int NQ, int K,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     void* workspace, size_t workspace_bytes, hipStream_t stream, bool unit_range) {
     if (!similarity_split_admissible(P, ldp, Q, ldq, NP, NQ, K))
         return fail(DIR_ERR_INVALID, "similarity_split: needs K % 32 == 0, ldp % 4 == 0 and a 16-byte aligned database");
     if (ldp < K || ldq < K || ldo < NP) return fail(DIR_ERR_INVALID, "similarity_split: ldp, ldq >= K and ldo >= NP");
     if (!workspace || workspace_bytes < similarity_split_workspace_bytes(NQ, K))
         return fail(DIR_ERR_WORKSPACE, "similarity_split: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return fail(DIR_ERR_INVALID, "similarity_split: workspace must be 16-byte aligned");
-    static std::atomic<uint64_t> attr_done{0}, attr_done_lc{0};
+    static std::atomic<uint64_t> attr_done{0}, attr_done_lc{0}, attr_done_pair{0};
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_kernel, kLds, attr_done));
-    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_lc_kernel, kLds, attr_done_lc));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_lc_kernel<false>, kLds, attr_done_lc));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_lc_kernel<true>, kLds2, attr_done_pair));
     static const bool v1 = getenv("DIRTORCH_AMD_SIM_V1") != nullptr;   // A/B and bisecting: the one-role kernel (read once)
     const int T = K / 32, qblocks = ceil_div(NQ, kQB);
-    hipLaunchKernelGGL(split_queries_kernel, dim3(T, qblocks), dim3(256), 0, stream, Q, ldq, NQ, K, (uint16_t*)workspace);
+    if (unit_range && !v1) {   // operands in (-64, 64): two fp16 planes, three products
+        hipLaunchKernelGGL(split_queries_kernel<true>, dim3(T, qblocks), dim3(256), 0, stream, Q, ldq, NQ, K, (uint16_t*)workspace);
+        hipLaunchKernelGGL(sim_split_lc_kernel<true>, dim3(ceil_div(NP, kRowsP), qblocks), dim3(768), kLds2, stream, P, ldp, NP, K,
+                           (const uint16_t*)workspace, out, ldo, NQ, T);
+        DIR_HIP_CHECK(hipGetLastError());
+        return DIR_OK;
+    }
+    hipLaunchKernelGGL(split_queries_kernel<false>, dim3(T, qblocks), dim3(256), 0, stream, Q, ldq, NQ, K, (uint16_t*)workspace);
     if (v1)
         hipLaunchKernelGGL(sim_split_kernel, dim3(ceil_div(NP, kRowsP), qblocks), dim3(512), kLds, stream, P, ldp, NP, K,
                            (const uint16_t*)workspace, out, ldo, NQ, T);
     else
-        hipLaunchKernelGGL(sim_split_lc_kernel, dim3(ceil_div(NP, kRowsP), qblocks), dim3(768), kLds, stream, P, ldp, NP, K,
+        hipLaunchKernelGGL(sim_split_lc_kernel<false>, dim3(ceil_div(NP, kRowsP), qblocks), dim3(768), kLds, stream, P, ldp, NP, K,
                            (const uint16_t*)workspace, out, ldo, NQ, T);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;

@@ -105,6 +105,7 @@ SIGNATURES = {
     'dir_pca_whiten_l2': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p, c_void_p]),
     'dir_similarity': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'dir_similarity_unit': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'dir_rank_counts': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     'dir_revisitop_ap': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

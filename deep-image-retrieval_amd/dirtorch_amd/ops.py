@@ -271,11 +271,13 @@ def gemm_nt(P, Q, qsub=None, bias=None, alpha=None):
     return out
 
 
-def similarity(queries, database):
+def similarity(queries, database, unit_range=False):
     """scores [Q, N] = queries . database^T, fp32 (dir_similarity).  Databases of >= 32768 rows with a width that
     is a multiple of 32 run as a three-plane bf16 split on the matrix cores (products to 2^-23, fp32
     accumulation; csrc/sim_split.hip), everything else - and everything under DIRTORCH_AMD_SIM_EXACT=1 - as
-    the k-ordered fp32 MFMA chain of gemm_nt."""
+    the k-ordered fp32 MFMA chain of gemm_nt.
+    unit_range=True (dir_similarity_unit): the caller guarantees |values| < 64 (L2-normalised descriptors) - two fp16
+    planes and half the matrix work on the large-database path; a larger value gives NON-FINITE scores, not wrong ones."""
     _need_cuda(queries, database)
     for t in (queries, database):
         if t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous():
@@ -287,7 +289,7 @@ def similarity(queries, database):
     out = torch.empty(Q, N, dtype=torch.float32, device=database.device)
     if Q == 0 or N == 0:
         return out
-    call('dir_similarity', ptr(queries), Q, ptr(database), N, D, ptr(out), stream_ptr())
+    call('dir_similarity_unit' if unit_range else 'dir_similarity', ptr(queries), Q, ptr(database), N, D, ptr(out), stream_ptr())
     return out
 
 

@@ -319,13 +319,21 @@ int dir_gemm_nt_f32(const float* P, int ldp, const float* Q, int ldq, float* out
  *                      with fp32 accumulation (csrc/sim_split.hip) - products to 2^-23, measured error against
  *                      fp64 below that of the k-ordered fp32 chain, 1.8x its speed; takes ceil(Q/96) * D * 576
  *                      bytes of stream-ordered scratch (hipMallocAsync).  Smaller databases, other widths and
- *                      DIRTORCH_AMD_SIM_EXACT=1 in the environment: the exact k-ordered chain of dir_gemm_nt_f32. */
+ *                      DIRTORCH_AMD_SIM_EXACT=1 in the environment: the exact k-ordered chain of dir_gemm_nt_f32.
+ *   dir_similarity_unit  the same product for operands the caller KNOWS to lie in (-64, 64) - L2-normalised
+ *                      descriptors, what common.matmul is called on in dirtorch/test_dir.py:150 - on the large-database
+ *                      path: every operand as two fp16 planes of 2^10 x (~22 bits), three plane products instead of
+ *                      six, scores rescaled by 2^-20: as accurate on unit vectors, 20+ % faster (the six-product form
+ *                      is matrix-pipe-bound).  A value of magnitude >= 64 overflows its plane to inf and the scores
+ *                      of its row come out NON-FINITE - never silently wrong.  Other sizes: identical to dir_similarity. */
 int dir_fc_l2(const float* x, int B, int K, const float* W, const float* b, int D, float* out,
               void* stream);
 int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components,
                       int v, const float* scale, int l2norm, float* out, void* stream);
 int dir_similarity(const float* queries, int Q, const float* database, int N, int D, float* scores,
                    void* stream);
+int dir_similarity_unit(const float* queries, int Q, const float* database, int N, int D, float* scores,
+                        void* stream);
 /* K10: multi-scale pooling of S descriptor sets [S][N][D] -> [N][D] (common.py:41-55):
  * mode 0 = mean, 1 = signed-power ("gem") mean with exponent gemp; no final L2 (caller does it). */
 int dir_multiscale_pool(const float* x, float* out, int S, int N, int D, int mode, float gemp,

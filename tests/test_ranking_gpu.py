@@ -300,6 +300,60 @@ def test_split_similarity_vs_fp64(Q, N, D, monkeypatch):
     assert float(got[0, 5]) == pytest.approx(1.0, abs=3e-7) and float(got[Q - 1, N - 1]) == pytest.approx(-1.0, abs=3e-7)
 
 
+@pytest.mark.parametrize('Q,N,D', [(70, 40000, 2048), (1, 33000, 64), (97, 32768 + 255, 512), (200, 50001, 128)])
+def test_pair_similarity_vs_fp64(Q, N, D):
+    """dir_similarity_unit (csrc/sim_split.hip PAIR: two fp16 planes of 2^10 x, three products) on unit vectors: against
+    fp64 it is held to the bound of the six-product kernel, and it must be at least as close as that kernel on the same
+    data; scores of exactly +-1; row tails, several query blocks, a single query."""
+    from dirtorch_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(Q * 7 + D)
+    db = torch.nn.functional.normalize(torch.randn(N, D, generator=g, device='cuda'), dim=1)
+    qs = torch.nn.functional.normalize(torch.randn(Q, D, generator=g, device='cuda'), dim=1)
+    db[5] = qs[0]
+    db[N - 1] = -qs[Q - 1]
+    ref = qs.double() @ db.double().t()
+    got = ops.similarity(qs, db, unit_range=True)
+    six = ops.similarity(qs, db)
+    err, err6 = float((got.double() - ref).abs().max()), float((six.double() - ref).abs().max())
+    print('\n[pair-similarity] %dx%dx%d: max |pair - fp64| %.2e, max |six-product - fp64| %.2e' % (Q, N, D, err, err6))
+    assert got.shape == (Q, N) and err < 2e-6
+    assert err <= err6 + 1e-7, (err, err6)
+    assert float(got[0, 5]) == pytest.approx(1.0, abs=3e-7) and float(got[Q - 1, N - 1]) == pytest.approx(-1.0, abs=3e-7)
+    assert torch.equal(got, ops.similarity(qs, db, unit_range=True))      # run-to-run identical
+
+
+def test_pair_similarity_range_and_selection():
+    """What the fp16 planes can hold: entries up to 60 in magnitude and down to 1e-6 keep fp32-class products (relative to
+    sum |q||d|); a value beyond 64 makes the scores of its row NON-FINITE (never silently wrong); ranking.similarity_device
+    looks before it picks the kernel; small databases are the exact chain either way."""
+    from dirtorch_amd import ops, ranking
+    Q, N, D = 40, 33000, 256
+    g = torch.Generator(device='cuda').manual_seed(6)
+    db = torch.randn(N, D, generator=g, device='cuda')
+    qs = torch.randn(Q, D, generator=g, device='cuda')
+    db[::3] *= 10.0                       # |values| up to ~52
+    db[1::3] *= 1e-5
+    db[7] = 0
+    qs[::2] *= 1e-3
+    assert ranking.is_unit_range(qs, db)
+    got = ops.similarity(qs, db, unit_range=True).double()
+    ref = qs.double() @ db.double().t()
+    scale = qs.double().abs() @ db.double().abs().t()
+    rel = (got - ref).abs() / scale.clamp_min(1e-300)
+    rel[:, 7] = 0
+    assert torch.isfinite(got).all() and float(got[:, 7].abs().max()) == 0.0
+    assert float(rel.max()) < 1e-6, float(rel.max())
+    assert torch.equal(ranking.similarity_device(qs, db), ops.similarity(qs, db, unit_range=True))
+    db[11, 3] = 100.0                     # outside the range
+    bad = ops.similarity(qs, db, unit_range=True)
+    assert not torch.isfinite(bad[:, 11]).all() and torch.isfinite(bad[:, :11]).all() and torch.isfinite(bad[:, 12:]).all()
+    assert not ranking.is_unit_range(qs, db)
+    safe = ranking.similarity_device(qs, db)              # ... so the default path takes the six-product kernel
+    assert torch.isfinite(safe).all() and torch.equal(safe, ops.similarity(qs, db))
+    small = db[:1000].contiguous()
+    assert torch.equal(ops.similarity(qs, small, unit_range=True), ops.similarity(qs, small))
+
+
 def test_split_similarity_keeps_the_fp32_exponent_range(monkeypatch):
     """Not only unit vectors: rows scaled by 2^+-40 (bf16 planes keep all 8 exponent bits, so no scaling step
     exists to go wrong), an all-zero row, and a database row pitch view.  Relative to sum_k |q_k||d_k| the
