@@ -1,7 +1,7 @@
 #!/bin/bash
-# the fp16-pair similarity kernel: tests, then the distractor workload with it and with the six-product kernel
+# the fp16-pair similarity kernel + the lock-step rank histogram: tests, then the distractor workload both ways
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 900 python -m pytest tests/test_ranking_gpu.py -q -x -s -k "similarity" 2>&1 | grep -E "^\[|passed|failed|^E " | cut -c1-200 | tail -n 24
+timeout 1200 python -m pytest tests/test_ranking_gpu.py -q -x 2>&1 | tail -n 3
 for mode in pair general; do
   if [ $mode = general ]; then X=--sim-general; else X=; fi
   timeout 600 python bench.py --workload distractors --steps 10 --warmup 3 --cpu-seconds 0 $X 2>/dev/null | python -c "
