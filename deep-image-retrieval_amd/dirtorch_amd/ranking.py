@@ -19,7 +19,12 @@ UNIT_RANGE_MIN_ROWS = 32768  # ... which only exists on the large-database path
 def is_unit_range(*tensors):
     """True when every value lies inside the fp16-pair similarity kernel's range (one abs-max pass per tensor, one
     host sync: call it once per database, not per query batch).  L2-normalised descriptors always qualify."""
-    return all(t.numel() == 0 or float(t.abs().max()) < UNIT_RANGE_BOUND for t in tensors)
+    for t in tensors:
+        if t.numel():
+            lo, hi = torch.aminmax(t)      # (no |t| temporary: the database is 8 GB at config D's sizes)
+            if not max(-float(lo), float(hi)) < UNIT_RANGE_BOUND:      # (NaN compares false: not in range)
+                return False
+    return True
 
 
 def similarity_device(qdescs, bdescs, unit_range=None):
