@@ -348,3 +348,33 @@ def test_sorted_probe_rank_counts_equal_the_definition():
     rank = np.empty(N, np.int64)
     rank[order] = np.arange(N)
     assert (want[1] == rank[probe[1]]).all()
+
+
+def test_unit_range_check_of_the_pair_similarity_kernel():
+    """ranking.is_unit_range: what decides between dir_similarity_unit (two fp16 planes of 2^10 x: operands in (-64, 64),
+    csrc/sim_split.hip PAIR) and the general six-product kernel.  L2-normalised descriptors qualify; anything at or beyond
+    the bound, NaN or inf does not; empty sets do; and the fp16 arithmetic it guards really holds such values: a plane of
+    2^10 * 60 is finite in fp16, one of 2^10 * 64 is not."""
+    import torch
+    from dirtorch_amd import ranking
+    g = torch.Generator().manual_seed(3)
+    d = torch.nn.functional.normalize(torch.randn(500, 64, generator=g), dim=1)
+    assert ranking.is_unit_range(d, d[:7])
+    assert ranking.is_unit_range(d * 59.0)
+    assert not ranking.is_unit_range(d, d * 1e4)
+    bad = d.clone()
+    bad[3, 5] = float('nan')
+    assert not ranking.is_unit_range(bad)
+    bad[3, 5] = float('-inf')
+    assert not ranking.is_unit_range(bad)
+    bad[3, 5] = -ranking.UNIT_RANGE_BOUND
+    assert not ranking.is_unit_range(bad)
+    assert ranking.is_unit_range(torch.zeros(0, 64), d)
+    assert torch.isfinite(torch.tensor(1024.0 * ranking.UNIT_RANGE_BOUND).half())
+    assert not torch.isfinite(torch.tensor(1024.0 * 64.0).half())
+    # the pair representation of a unit-vector entry: hi + lo of 2^10 x holds x to ~2^-22
+    x = d.flatten()[:4096].double()
+    hi = (x * 1024).float().half()
+    lo = ((x * 1024).float() - hi.float()).half()
+    rec = (hi.double() + lo.double()) / 1024
+    assert float((rec - x).abs().max()) < 2.0 ** -22 * float(x.abs().max()) + 2.0 ** -35
