@@ -378,3 +378,36 @@ def test_unit_range_check_of_the_pair_similarity_kernel():
     lo = ((x * 1024).float() - hi.float()).half()
     rec = (hi.double() + lo.double()) / 1024
     assert float((rec - x).abs().max()) < 2.0 ** -22 * float(x.abs().max()) + 2.0 ** -35
+
+
+def test_pair_similarity_arithmetic_restated_in_numpy():
+    """The arithmetic of csrc/sim_split.hip's PAIR form, restated: x * 2^10 = h + l (fp16 planes), score = (h.h' + h.l' + l.h')
+    * 2^-20 with exact plane products (11 x 11 bits) summed in wider precision.  On unit vectors that is an fp32-class dot
+    product (what the GPU test measures against fp64: 2.5e-7 incl. the fp32 accumulation of the matrix cores); one plane alone
+    is fp16-class; and the dropped l.l' term is below 2^-22 of the sum of |products|."""
+    r = np.random.RandomState(4)
+    Q, N, D = 16, 300, 2048
+    q = r.standard_normal((Q, D))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    d = r.standard_normal((N, D))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q, d = q.astype(np.float32), d.astype(np.float32)
+    d[5] = q[0]
+
+    def planes(x):
+        s = (x * np.float32(1024.0)).astype(np.float32)      # exact: a power of two
+        h = s.astype(np.float16)
+        lo = (s - h.astype(np.float32)).astype(np.float16)    # s - h is exact in fp32
+        return h.astype(np.float64), lo.astype(np.float64)
+
+    qh, ql = planes(q)
+    dh, dl = planes(d)
+    ref = q.astype(np.float64) @ d.astype(np.float64).T
+    pair = (qh @ dh.T + (qh @ dl.T + ql @ dh.T)) / 2.0 ** 20
+    one = (qh @ dh.T) / 2.0 ** 20
+    e_pair, e_one = np.abs(pair - ref).max(), np.abs(one - ref).max()
+    assert e_pair < 1e-7, e_pair                     # representation + dropped term only (largest on the score of 1: l.l adds up)
+    assert e_one > 100 * e_pair                      # a single plane is three decimal digits worse
+    assert abs(pair[0, 5] - 1.0) < 1e-7
+    dropped = np.abs(ql @ dl.T) / 2.0 ** 20
+    assert dropped.max() < 2.0 ** -22 * (np.abs(q).astype(np.float64) @ np.abs(d).astype(np.float64).T).max()
