@@ -26,8 +26,9 @@
 // launch less; one 16-bit rounding less than the reference's storage points).
 //
 // WP3 / WP1 (DIR_FP16P, fp16 only): the weights of conv3 (+ downsample) / of conv1' are fp16 PAIRS (hi + lo planes, ~22 bits:
-// csrc/conv_pair.hip); the lo planes sit in registers next to the hi ones and every product term costs a second MFMA -
-// free on these HBM-bound seams (MfmaUtil 0.13-0.24 single).  In the DS form the block input (the stem's pooled output)
+// csrc/conv_pair.hip); the lo planes sit in registers next to the hi ones and every product term costs a second MFMA - no
+// bytes, and little time on these HBM-bound seams (MfmaUtil 0.13-0.24 single; measured at batch 32: 0.51-0.59 ms against
+// 0.47-0.55, the DS form 0.52-0.58 against 0.38 - its MFMA phases sit between barriers).  In the DS form the block input (the stem's pooled output)
 // is a pair too: its lo plane is staged as a third 64-channel K block that multiplies the downsample's HI weights (the
 // lo x lo term, 2^-22 relative, is dropped as everywhere in the paired head).
 //

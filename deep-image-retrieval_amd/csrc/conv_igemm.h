@@ -29,7 +29,7 @@ struct ConvArgs {
     // folded into this GEMM): x2 [M][Cin2], its weights appended to w along K, its bias added to bias
     const uint16_t* x2;
     int Cin2;
-    // ... or (implicit-GEMM DUAL form, conv_igemm.hip) any 1x1 downsample: x2 is NHWC [B,H2,W2,Cin2], output
+    // ... or (two-source GEMM, conv_persist.hip DUAL) any 1x1 downsample: x2 is NHWC [B,H2,W2,Cin2], output
     // pixel (b, oh, ow) reads x2 pixel (b, oh*stride2, ow*stride2)
     int H2, W2, stride2;
     uint32_t x2_bytes;

@@ -121,7 +121,7 @@ struct dir_engine {
     int run_seam(dir::ConvLayer& c3, dir::ConvLayer& c1, const uint16_t* t2, const uint16_t* res, uint16_t* y,
                  uint16_t* t1, int B, int H, int W, hipStream_t stream, int* used,
                  const uint16_t* block_in = nullptr, const uint16_t* block_in_lo = nullptr);
-    // conv3 + the block's 1x1 downsample branch as ONE two-source GEMM (conv_igemm.hip DUAL form); dry = only
+    // conv3 + the block's 1x1 downsample branch as ONE two-source GEMM (conv_persist.hip DUAL form); dry = only
     // report whether it would run (decided before the downsample would be launched)
     int run_conv_dual(dir::ConvLayer& c3, const dir::ConvLayer& ds, const uint16_t* t2, const uint16_t* xin,
                       uint16_t* y, int B, int Hin, int Win, int OH, int OW, hipStream_t stream, int* used, bool dry);

@@ -245,7 +245,7 @@ int dir_engine::finalize(int dt) {
     // input.  Its weights are appended to conv3's along K and the biases summed, so that
     // relu([W3 | Wds] . [t2 ; x_s] + b3 + bds) is ONE GEMM and the Cout-wide residual tensor is never
     // materialised: conv_c3c1's DS form (layer1: 64 + 64 channels, stride 1) or the two-source form of the
-    // implicit-GEMM kernel (layers 2-4, stride 2).
+    // persistent 1x1 kernel (conv_persist.hip DUAL: layers 2-4, stride 2).
     for (const BlockDef& bd : blocks) {
         if (!desc.bottleneck || bd.down < 0 || bd.conv3 < 0 || dt == DIR_F32) continue;
         ConvLayer& c3 = convs[bd.conv3];
@@ -941,7 +941,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             ds_in_seam = !sw.c3c1_off && !sw.no_ds_seam && (sw.c3c1_force || ((long)B * oh * ow + 63) / 64 >= kSeamMinTiles) &&
                          (long)B * oh * ow * convs[bd.conv3].Cout < (1L << 30);
         }
-        // the other stages' first blocks: conv3 + downsample as one two-source GEMM (conv_igemm.hip, DUAL)
+        // the other stages' first blocks: conv3 + downsample as one two-source GEMM (conv_persist.hip, DUAL)
         int ds_dual = 0;
         if (bd.down >= 0 && !ds_in_seam && desc.bottleneck && !tuning && !cur_lo) {
             rc = run_conv_dual(convs[bd.conv3], convs[bd.down], t2, cur, nxt, B, h, w, oh, ow, stream, &ds_dual, true);

@@ -52,12 +52,15 @@ typedef enum dir_dtype {
     DIR_FP16 = 1,             /* fp16 storage, fp16 MFMA: 11-bit mantissa, saturates at 65504 (dir_engine_overflow) */
     DIR_F32 = 2,              /* STRICT: fp32 storage and products on the fp32 matrix cores (conv_f32.hip) - the
                                  reference's own arithmetic up to summation order; ~1/8 of the 16-bit throughput */
-    DIR_FP16P = 3             /* fp16 with a PAIRED head: the image, the stem and layer1 - where a conditioned network
-                                 makes ~94 % of its 16-bit rounding error - are stored as pairs of fp16 planes
-                                 (v ~ hi + lo, ~22 bits) and multiplied with three fp16 MFMAs per term (conv_pair.hip);
-                                 layers 2-4 are DIR_FP16.  Meets the 1e-4 cosine bar on BatchNorm-calibrated
-                                 checkpoints at ~3/4 of the fp16 throughput.  DIRTORCH_AMD_PAIR_STAGES=1..4 (read at
-                                 finalize) extends the paired region to later stages. */
+    DIR_FP16P = 3             /* fp16 with a PAIRED head: where a conditioned network makes ~94 % of its 16-bit rounding
+                                 error (the image, the stem, layer1) values are kept as pairs of fp16 planes (v ~ hi + lo,
+                                 ~22 bits) and multiplied with two or three fp16 MFMAs per term - the image, the stem's
+                                 weights and pooled output, and the weights of layer1's 1x1 convs (conv_pair.hip,
+                                 conv_c3c1.hip WP); everything else is DIR_FP16.  Meets the 1e-4 cosine bar on
+                                 BatchNorm-calibrated checkpoints (3.3e-5 ... 4.3e-5) at ~94 % of the fp16 throughput.
+                                 Read at finalize: DIRTORCH_AMD_PAIR_ACTS=1 also pairs layer1's 3x3 weights and the
+                                 tensors inside its blocks (1.5e-5 ... 1.7e-5, ~83 %; always on for BasicBlock nets),
+                                 DIRTORCH_AMD_PAIR_STAGES=1..4 extends the paired region to later stages. */
 } dir_dtype;
 
 typedef enum dir_img_format {
@@ -227,7 +230,7 @@ int dir_conv_c3c1(const void* t2, const void* w3, const float* bias3, const void
                   const float* bias1, void* t1, int B, int H, int W, int P, int P2, int relu3, int relu1, int dtype,
                   void* stream);
 /* conv3 + bn3 + the block's downsample branch + add + ReLU of a stage's FIRST bottleneck as one GEMM over
- * two K sources (csrc/conv_igemm.hip, DUAL form; dirtorch/nets/backbones/resnet.py:78-85 with :134-141):
+ * two K sources (csrc/conv_persist.hip, DUAL form: the persistent deep-X ring with a second pixel source; dirtorch/nets/backbones/resnet.py:78-85 with :134-141):
  *   y[b,oh,ow,:] = act([w3 | wds] . [t2[b,oh,ow,:] ; x[b,oh*stride2,ow*stride2,:]] + bias),  bias = bias3 + bias_ds
  * t2 [B,OH,OW,Cin], x [B,H2,W2,Cin2] NHWC 16-bit, wcat [Cout][Cin + Cin2], Cout % 256 == 0, Cin, Cin2 % 64 == 0.
  * The Cout-wide residual tensor is neither written nor read. */
@@ -243,7 +246,7 @@ int dir_conv_c3c1_ds(const void* t2, const void* x, const void* wcat, const floa
                      void* stream);
 /* Both seams with PAIRED WEIGHTS (DIR_FP16P, fp16 only; csrc/conv_c3c1.hip WP3 / WP1): every weight matrix comes as two
  * fp16 planes, value = hi + lo with lo = fp16(w - hi) (~22 bits), and every product term costs two MFMAs instead of one -
- * free on these HBM-bound kernels.  Activations are single fp16 planes, except the block input x of the DS form (the
+ * no extra bytes on these HBM-bound kernels (measured: +6-9 % time, +35 % for the DS form with its third K block).  Activations are single fp16 planes, except the block input x of the DS form (the
  * stem's pooled output), which is a pair as well: [w3 | wds] . [t2 ; x_hi + x_lo] with the lo x lo term dropped.
  * P = 64 (layer1: dirtorch/nets/backbones/resnet.py:67-87, 134-141); P2 = 64 needs w1_lo, P2 = 128 (the layer1 ->
  * layer2 boundary, whose conv1 belongs to layer2) takes w1_lo = NULL for single-plane weights there. */
