@@ -9,7 +9,7 @@ A "step" is one pass of the hot path (dir_forward: prep -> trunk -> GeM -> FC ->
 of synthetic normalised images that is already resident in HBM.  Database images are sharded
 image-parallel over the ranks (no data-path collective inside a step); after the K steps each rank
 all-gathers its shard's descriptor block once over RCCL/xGMI (the one exchange step the path has,
-inside the timed region for N > 1).  Weights are the deterministic synthetic checkpoint of
+inside the timed region for N > 1; the same collective has run once before the clock starts).  Weights are the deterministic synthetic checkpoint of
 tests/synth.py (there is no network for real ones); oracle/ is imported by the cpu_baseline leg only.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -27,7 +27,9 @@ The timed loops run with the Python cycle collector off (a full collection in th
 
 Two more workloads keep the same flags and JSON contract (the default above is BASELINE configs[1]):
   --workload distractors   configs[3]: 70 x 1 006 322 x 2048 similarity + device rank / AP, the database sharded over
-                           the ranks, ONE all-gather of descriptor (or --exchange scores: score) blocks
+                           the ranks, ONE all-gather of descriptor (or --exchange scores: score) blocks; the descriptors
+                           are L2-normalised, so the similarity runs on two fp16 planes (dir_similarity_unit; the range is
+                           established once per database, outside the timed steps; --sim-general = the six-product bf16 kernel)
   --workload multiscale    configs[4]: three scales of resident uint8 1200^2 images, fp16, device-side resize
 """
 import argparse
