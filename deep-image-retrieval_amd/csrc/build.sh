@@ -1,14 +1,25 @@
 #!/bin/bash
 # Builds libdir_engine.so for gfx950 (cross-compiles without a GPU). Usage: csrc/build.sh [-j N]
+#   DIR_EXPERIMENTS=1 csrc/build.sh   an EXPERIMENTS build: + conv_ring.hip (128x256_ring1x1: ties conv_persist.hip inside the
+#                                     network) and conv_seam3.hip (layer3's conv3 -> conv1 seam: loses to the two kernels it
+#                                     replaces, profiles/r04_seam3_ablation.txt), compiled with -DDIR_EXPERIMENTS into
+#                                     dirtorch_amd/libdir_engine_exp.so - select it with DIRTORCH_AMD_LIB=<that path> and
+#                                     DIRTORCH_AMD_EXPERIMENTS=1.  The default library ships neither kernel.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../dirtorch_amd/libdir_engine.so"
-OBJ="$HERE/_build"
-mkdir -p "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-but-set-variable"
+SRCS="conv_f32 conv_pair conv_igemm conv_patch conv_patchlc conv_patchw conv_persist conv_wreg conv_c3c1 stem_pool pointwise resize gemm_f32 sim_split ranking comm engine c_api"
+if [ -n "${DIR_EXPERIMENTS:-}" ]; then
+  OUT="$HERE/../dirtorch_amd/libdir_engine_exp.so"; OBJ="$HERE/_build_exp"; FLAGS="$FLAGS -DDIR_EXPERIMENTS"; SRCS="$SRCS conv_ring conv_seam3"
+else
+  OUT="$HERE/../dirtorch_amd/libdir_engine.so"; OBJ="$HERE/_build"
+fi
+mkdir -p "$OBJ"
 pids=()
-for src in conv_f32 conv_pair conv_igemm conv_patch conv_patchlc conv_patchw conv_persist conv_ring conv_wreg conv_c3c1 conv_seam3 stem_pool pointwise resize gemm_f32 sim_split ranking comm engine c_api; do
+objs=()
+for src in $SRCS; do
+  objs+=("$OBJ/$src.o")
   if [ ! -f "$OBJ/$src.o" ] || [ -n "$(find "$HERE" -maxdepth 1 \( -name '*.h' -o -name "$src.hip" \) -newer "$OBJ/$src.o")" ] \
      || [ "$HERE/../../include/dir_engine.h" -nt "$OBJ/$src.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OBJ/$src.o" &
@@ -16,5 +27,5 @@ for src in conv_f32 conv_pair conv_igemm conv_patch conv_patchlc conv_patchw con
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -ldl -o "$OUT" "$OBJ"/conv_f32.o "$OBJ"/conv_pair.o "$OBJ"/conv_igemm.o "$OBJ"/conv_patch.o "$OBJ"/conv_patchlc.o "$OBJ"/conv_patchw.o "$OBJ"/conv_persist.o "$OBJ"/conv_ring.o "$OBJ"/conv_wreg.o "$OBJ"/conv_c3c1.o "$OBJ"/conv_seam3.o "$OBJ"/stem_pool.o "$OBJ"/pointwise.o "$OBJ"/resize.o "$OBJ"/gemm_f32.o "$OBJ"/sim_split.o "$OBJ"/ranking.o "$OBJ"/comm.o "$OBJ"/engine.o "$OBJ"/c_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -ldl -o "$OUT" "${objs[@]}"
 echo "built $OUT"

@@ -31,6 +31,11 @@ extern "C" {
 const char* dir_last_error(void) { return last_error(); }
 const char* dir_version(void) { return "dir_engine 0.1 gfx950"; }
 
+int dir_reload_env(void) {
+    dir::reload_env();
+    return DIR_OK;
+}
+
 int dir_engine_create(const dir_model_desc* desc, int device, dir_engine** out) {
     DIR_TRY
     if (!desc || !out) return fail(DIR_ERR_INVALID, "create: null argument");
@@ -50,6 +55,7 @@ int dir_engine_create(const dir_model_desc* desc, int device, dir_engine** out) 
     dir_engine* e = new dir_engine();
     e->desc = *desc;
     e->device = device;
+    e->sw = dir::env();   // the A/B switches as they stand now; forward() never reads the environment
     int rc = e->build_graph();
     if (rc != DIR_OK) {
         delete e;
@@ -205,7 +211,12 @@ int dir_prep_input_pair(const void* img, int img_format, const float* mean3, con
 int dir_stem_pool_pair(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
                        void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, void* stream) {
     DIR_TRY
+    if (!s2d_hi || !s2d_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo) return fail(DIR_ERR_INVALID, "stem_pool_pair: null pointer");
     if (B <= 0 || H2 <= 0 || W2 <= 0 || OH <= 0 || OW <= 0) return fail(DIR_ERR_INVALID, "stem_pool_pair: bad dimension");
+    // the 7x7 s2 p3 conv of an H x W image has (H - 1) / 2 + 1 = (H + 1) / 2 output rows - the rows of its space-to-depth
+    // grid, for even and odd H alike; any other OH / OW would size the grid and the stores beyond the caller's buffers
+    if (OH != H2 || OW != W2)
+        return fail(DIR_ERR_INVALID, "stem_pool_pair: OH x OW must equal the space-to-depth grid H2 x W2 (conv 7x7 s2 p3)");
     return stem_pool_pair_launch(s2d_hi, s2d_lo, w_hi, w_lo, bias, y_hi, y_lo, B, H2, W2, OH, OW, (hipStream_t)stream);
     DIR_CATCH
 }
@@ -358,6 +369,21 @@ int dir_conv_heuristic(int B, int H, int W, int Cin, int Cout, int R, int S, int
     strncpy(name, conv_variant(v).name, cap - 1);
     name[cap - 1] = 0;
     if (ksplit) *ksplit = conv_splitk_factor(v, a);
+    return DIR_OK;
+    DIR_CATCH
+}
+
+int dir_conv_variant_admissible(int variant, int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                int OH, int OW, int has_residual, int* admissible) {
+    DIR_TRY
+    if (!admissible) return fail(DIR_ERR_INVALID, "conv_variant_admissible: null result pointer");
+    if (variant < 0 || variant >= conv_variant_count()) return fail(DIR_ERR_INVALID, "conv_variant_admissible: no such variant");
+    ConvArgs a;
+    static const float dummy = 0.f;   // host-only decision: the pointers are never dereferenced
+    int rc = fill_conv_args(a, &dummy, &dummy, &dummy, has_residual ? &dummy : nullptr, (void*)&dummy, B, H, W, Cin,
+                            Cout, R, S, stride, pad, OH, OW, 1);
+    if (rc != DIR_OK) return rc;
+    *admissible = conv_variant_admissible(variant, a) ? 1 : 0;
     return DIR_OK;
     DIR_CATCH
 }
@@ -572,6 +598,8 @@ int dir_stem_pool(const void* s2d, const void* w, const float* bias, void* y, in
     DIR_TRY
     if (!s2d || !w || !bias || !y || B <= 0 || H2 <= 0 || W2 <= 0 || OH <= 0 || OW <= 0)
         return fail(DIR_ERR_INVALID, "stem_pool: bad argument");
+    if (OH != H2 || OW != W2)   // (conv 7x7 s2 p3: (H - 1) / 2 + 1 == (H + 1) / 2 for every H; see dir_stem_pool_pair)
+        return fail(DIR_ERR_INVALID, "stem_pool: OH x OW must equal the space-to-depth grid H2 x W2 (conv 7x7 s2 p3)");
     return stem_pool_launch(s2d, w, bias, y, B, H2, W2, OH, OW, dtype, (hipStream_t)stream);
     DIR_CATCH
 }
@@ -672,7 +700,7 @@ static int similarity_impl(const float* queries, int Q, const float* database, i
     // products, ~2x the speed of the exact fp32 MFMA chain (sim_split.hip) - or, for operands the caller knows to be
     // bounded (dir_similarity_unit), two fp16 planes and half the products.  Small ones, odd widths and
     // DIRTORCH_AMD_SIM_EXACT=1 keep the k-ordered fmaf chain of gemm_nt_f32.
-    const bool exact = getenv("DIRTORCH_AMD_SIM_EXACT") != nullptr;   // read per call: a ms-scale operation
+    const bool exact = dir::env().sim_exact;
     if (!exact && N >= kSimSplitMinRows && similarity_split_admissible(database, D, queries, D, N, Q, D)) {
         const size_t bytes = similarity_split_workspace_bytes(Q, D);
         void* ws = nullptr;

@@ -364,7 +364,9 @@ bool conv_c3c1_admissible(const ConvArgs& a) {
     // either a tensor (a.res) or - DS form, planes 64 - the 64-channel block input a.x2, whose
     // downsample weights are concatenated to a.w along K ([Cout][64 + 64]) and biases summed in a.bias
     const bool ds = a.x2 != nullptr;
-    if (a.Cin == 256) return conv_seam3_admissible(a);     // layer3: the streamed-weights form (conv_seam3.hip)
+#ifdef DIR_EXPERIMENTS
+    if (a.Cin == 256) return conv_seam3_admissible(a);     // layer3: the streamed-weights form (conv_seam3.hip, experiments builds)
+#endif
     return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW &&
            (a.Cin == 64 || a.Cin == 128) && a.Cout == 4 * a.Cin && (ds ? (a.res == nullptr && a.Cin == 64 && a.Cin2 == 64)
                                                                        : a.res != nullptr) &&
@@ -393,7 +395,9 @@ static hipError_t launch_c3c1(const ConvArgs& a, hipStream_t stream) {
 }
 
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
+#ifdef DIR_EXPERIMENTS
     if (a.Cin == 256) return conv_seam3_launch(a, dtype, stream);
+#endif
     if (a.w_lo) {   // DIR_FP16P: conv3's (+ downsample's) weights are pairs; conv1's are when they belong to layer1 too
         if (dtype != DIR_FP16) return hipErrorInvalidValue;
         if (a.x2) return a.w2_lo ? launch_c3c1<FP16, 64, true, 64, true, true>(a, stream) : hipErrorInvalidValue;

@@ -484,7 +484,9 @@ static const ConvVariant kVariants[] = {
      {conv1x1_persist_dual_bf16, conv1x1_persist_dual_fp16}},
     // persistent 128x256 tile, loader waves feed ONE three-slot K ring over all the tiles of a workgroup, consumer waves
     // multiply; 1x1 convs without a residual (conv_ring.hip)
+#ifdef DIR_EXPERIMENTS   // (csrc/build.sh with DIR_EXPERIMENTS=1: ties conv_persist.hip inside the network, not a default build's kernel)
     {"128x256_ring1x1", 128, 256, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 7, {nullptr, nullptr}, {nullptr, nullptr}},
+#endif
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
     {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}, {nullptr, nullptr}},
 };
@@ -502,7 +504,9 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 2) return conv1x1_persist_admissible(a);
     if (cv.kind == 4) return conv1x1_persist_admissible(a) && a.res == nullptr;   // the deep-X form has no residual path
     if (cv.kind == 3) return conv1x1_wreg_admissible(a);
+#ifdef DIR_EXPERIMENTS
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
+#endif
     if (cv.kind == 8) return conv_patch64_lc_admissible(a);
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
@@ -530,7 +534,7 @@ static int find_variant(const char* name) {
 int conv_pick_variant(const ConvArgs& a) {
     {
         // layer1's 64 -> 64 3x3: filter resident in LDS, loader / consumer waves (DIRTORCH_AMD_NO_PATCHLC: A/B and bisecting)
-        static const bool no_lc = getenv("DIRTORCH_AMD_NO_PATCHLC") != nullptr;
+        const bool no_lc = env().no_patchlc;
         const int v = find_variant("256x64_patchlc3x3");
         if (!no_lc && v >= 0 && conv_variant_admissible(v, a) &&
             (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) >= 192)
@@ -541,7 +545,7 @@ int conv_pick_variant(const ConvArgs& a) {
     // the residual 1x1 convs with K <= 256 (layer2/3 conv3): weights stationary in registers, as long
     // as every persistent workgroup gets at least ~4 pixel tiles to amortise loading them
     {
-        static const bool no_wreg = getenv("DIRTORCH_AMD_NO_WREG") != nullptr;   // A/B and bisecting
+        const bool no_wreg = env().no_wreg;   // A/B and bisecting
         const int v = find_variant("64x512_wreg1x1");
         if (!no_wreg && v >= 0 && conv_variant_admissible(v, a) &&
             (long)ceil_div(a.M, 64) * (a.Cout / 512) >= 1024)
@@ -556,7 +560,7 @@ int conv_pick_variant(const ConvArgs& a) {
         // double-buffered 32-channel planes (conv_patchw.hip) - A/B at batch 32 (gpurun_out/pw): layer2 175 -> 153 us,
         // layer3 133 -> 124 us, layer4 121 -> 113 us.  Falls through (like every candidate) when it is not admissible
         // or leaves CUs without a tile.
-        static const bool no_pw = getenv("DIRTORCH_AMD_NO_PATCHW") != nullptr;   // A/B and bisecting
+        const bool no_pw = env().no_patchw;   // A/B and bisecting
         if (!no_pw && a.R * a.S > 1 && a.Cin >= 128) c[n++] = {"512x128_patch3x3w", 1};
     }
     if (T <= 1 || a.Cout % 128 != 0) {
@@ -566,16 +570,17 @@ int conv_pick_variant(const ConvArgs& a) {
         // 1x1 without a residual and a very long K loop (the 2048 -> 512 conv1 of layer4): the deep-X ring.
         // A/B at batch 32 (gpurun_out/r2b): 81 -> 71 us there, but 87 -> 90 us on layer3's 1024 -> 256 -
         // those are not short of HBM requests in flight, so they keep the 2-slot form.
-        static const bool no_x3 = getenv("DIRTORCH_AMD_NO_X3") != nullptr;      // A/B and bisecting
+        const bool no_x3 = env().no_x3;      // A/B and bisecting
         const bool x3 = a.R * a.S == 1 && !a.res && !no_x3 && T >= 32;
         // 3x3 over 256 / 512 channels: the plane-at-a-time patch kernel (conv_patch.hip) - falls through to the
         // 16-wave implicit-GEMM tile where it is not admissible (stride 2, odd widths) or too few tiles
-        static const bool no_ps = getenv("DIRTORCH_AMD_NO_PATCHS") != nullptr;  // A/B and bisecting
+        const bool no_ps = env().no_patchs;  // A/B and bisecting
         if (a.R * a.S > 1 && !no_ps) c[n++] = {"256x256_patch3x3s", 1};
         // (conv_ring.hip's 128x256_ring1x1 - split loader / consumer waves - ties the persistent kernel on these layers
         // inside the network, gpurun_out/r3f-r3h: it stays a tuner candidate; DIRTORCH_AMD_RING=1 puts it first, for A/B)
-        static const bool ring = getenv("DIRTORCH_AMD_RING") != nullptr;
-        if (a.R * a.S == 1 && !a.res && ring) c[n++] = {"128x256_ring1x1", 1};
+#ifdef DIR_EXPERIMENTS
+        if (a.R * a.S == 1 && !a.res && env().experiments) c[n++] = {"128x256_ring1x1", 1};
+#endif
         c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
@@ -732,7 +737,9 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
                    : cv.kind == 2 ? conv1x1_persist_launch(a, dtype, stream)
                    : cv.kind == 4 ? conv1x1_persist_launch(a, dtype, stream, true)
                    : cv.kind == 3 ? conv1x1_wreg_launch(a, dtype, stream)
+#ifdef DIR_EXPERIMENTS
                    : cv.kind == 7 ? conv1x1_ring_launch(a, dtype, stream)
+#endif
                    : cv.kind == 8 ? conv_patch64_lc_launch(a, dtype, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);

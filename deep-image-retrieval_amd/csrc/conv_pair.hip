@@ -577,7 +577,7 @@ static bool pair_wide(const ConvArgs& a) { return a.Cout % 128 == 0; }
 
 // DIRTORCH_AMD_NO_PAIR_PATCH=1: layer1's 3x3 back on the implicit-GEMM form (A/B and bisecting; read per call)
 static bool use_pair_patch64(const ConvArgs& a) {
-    return pair_patch64_admissible(a) && getenv("DIRTORCH_AMD_NO_PAIR_PATCH") == nullptr;
+    return pair_patch64_admissible(a) && !env().no_pair_patch;
 }
 
 const char* conv_pair_variant_name(const ConvArgs& a) {
@@ -1004,7 +1004,7 @@ int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_
     a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
     a.ovf = ovf;
     const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
-    const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting (read per launch: the tests flip it)
+    const bool v1 = env().stem_v1;   // A/B and bisecting (dir_reload_env after flipping it)
     if (!v1) {
         constexpr int LDSP = 2 * 2 * 2 * 512 * 16 + 8 * 32 * 256 + 256;   // two patch pairs + the fp32 conv tile + bias
         static std::atomic<uint64_t> attr_p{0};

@@ -358,7 +358,7 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     if (DUAL) b.x2_bytes = (uint32_t)((size_t)a.B * a.H2 * a.W2 * a.Cin2 * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
-    static const bool no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting (read once)
+    const bool no_xcd_map = env().no_xcdmap;   // A/B and bisecting
     b.no_xcd_map = no_xcd_map;
     // exact n / d for n < 2^31 (same constants as conv_igemm.hip)
     auto fd = [](uint32_t d, uint32_t& mul, uint32_t& shr) {

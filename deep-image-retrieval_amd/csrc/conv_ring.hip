@@ -291,7 +291,7 @@ static hipError_t launch_ring(const ConvArgs& a, hipStream_t stream) {
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     b.flat = (a.stride == 1 && a.H == a.OH && a.W == a.OW);
-    static const bool no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting (read once)
+    const bool no_xcd_map = env().no_xcdmap;   // A/B and bisecting
     b.no_xcd_map = no_xcd_map;
     auto fd = [](uint32_t d, uint32_t& mul, uint32_t& shr) {   // exact n / d for n < 2^31 (as in conv_igemm.hip)
         if (d <= 1) { mul = 0; shr = 0; return; }

@@ -357,7 +357,10 @@ __global__ void __launch_bounds__(512) conv_seam3_kernel(const ConvArgs a) {
 bool conv_seam3_admissible(const ConvArgs& a) {
     return a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW && a.Cin == 256 &&
            a.Cout == 1024 && a.Cout2 == 256 && a.res != nullptr && a.x2 == nullptr && a.w2 != nullptr && a.bias2 != nullptr &&
-           a.y2 != nullptr && a.M % 64 == 0 && (long)a.M * a.Cout < (1L << 30);
+           a.y2 != nullptr && a.M % 64 == 0 && (long)a.M * a.Cout < (1L << 30) &&
+           // single fp16 / bf16 planes only: with paired weights (DIR_FP16P, DIRTORCH_AMD_PAIR_STAGES >= 3) the seam is declined
+           // and the layers run on conv_pair.hip - this kernel would silently drop the lo planes
+           a.w_lo == nullptr && a.w2_lo == nullptr && a.x2_lo == nullptr;
 }
 
 template <class DT>

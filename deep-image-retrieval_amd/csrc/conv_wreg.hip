@@ -252,7 +252,7 @@ static hipError_t launch_wreg(const ConvArgs& a, hipStream_t stream) {
     const int mt = (a.M + 63) / 64;
     int per = 256 / nsl;                       // one persistent workgroup per CU
     if (per > mt) per = mt;
-    static const bool no_xcd_map = getenv("DIRTORCH_AMD_NO_XCDMAP") != nullptr;   // A/B and bisecting (read once)
+    const bool no_xcd_map = env().no_xcdmap;   // A/B and bisecting
     b.no_xcd_map = no_xcd_map;
     hipLaunchKernelGGL(kern, dim3(per * nsl), dim3(512), LDS, stream, b);
     return hipGetLastError();

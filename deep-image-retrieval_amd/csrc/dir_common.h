@@ -35,6 +35,26 @@ int fail(int code, const std::string& msg);
             return ::dir::fail(DIR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// ---- A/B switches --------------------------------------------------------------------------------------
+// Every DIRTORCH_AMD_* switch the library honours.  The environment is read ONCE (first use) and again only when the
+// host calls dir_reload_env() - what a test or an A/B script does after flipping a variable inside one process; an
+// engine copies the switches that steer its forward at dir_engine_create.  No launch path calls getenv.
+struct Env {
+    bool c3c1_off = false, c3c1_force = false;   // DIRTORCH_AMD_C3C1 = 0 | force: the fused conv3 -> conv1 seam kernels
+    bool no_ds_seam = false, no_dual = false;    // ..._NO_DS_SEAM, ..._NO_DUAL: the downsample as its own launch again
+    bool rev_conv1 = false, rev_conv3 = false;   // ..._REV_CONV1 / _REV_CONV3: reversed tile order (measured, no gain)
+    bool unfused_stem = false, stem_v1 = false;  // ..._UNFUSED_STEM, ..._STEM_V1: conv + maxpool apart / one tile per workgroup
+    bool no_patchlc = false, no_wreg = false, no_patchw = false, no_x3 = false, no_patchs = false;   // heuristic: skip a kernel
+    bool no_xcdmap = false;                      // ..._NO_XCDMAP: plain tile order in the persistent 1x1 kernels
+    bool no_pair_patch = false, pair_acts = false;   // DIR_FP16P: ..._NO_PAIR_PATCH, ..._PAIR_ACTS
+    int pair_stages = 1;                         // ..._PAIR_STAGES = 1..4 (validated at finalize)
+    bool sim_v1 = false, sim_exact = false;      // ..._SIM_V1 (one-role kernel), ..._SIM_EXACT (fp32 MFMA chain at any size)
+    bool experiments = false;                    // ..._EXPERIMENTS: opt-in kernels of an experiments build (conv_ring / conv_seam3)
+    bool inplace = false;                        // ..._INPLACE: conv3 writes the block output over the block input (round-5 probe)
+};
+const Env& env();
+void reload_env();
+
 // ---- 16-bit float conversions (host + device) ------------------------------------------------
 __host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
     uint32_t u;

@@ -125,11 +125,9 @@ struct dir_engine {
     // report whether it would run (decided before the downsample would be launched)
     int run_conv_dual(dir::ConvLayer& c3, const dir::ConvLayer& ds, const uint16_t* t2, const uint16_t* xin,
                       uint16_t* y, int B, int Hin, int Win, int OH, int OW, hipStream_t stream, int* used, bool dry);
-    // A/B switches, read from the environment ONCE per forward() (tests toggle them between calls; a getenv
-    // per block would cost tens of microseconds of a 1.5 ms batch-1 step)
-    struct Switches {
-        bool c3c1_off = false, c3c1_force = false, no_ds_seam = false, no_dual = false, no_seam3 = false, rev_conv1 = false, rev_conv3 = false;
-    } sw;
+    // A/B switches: the process-wide dir::env() as it stood at dir_engine_create (tests build a new engine after
+    // flipping a variable and calling dir_reload_env); forward() never reads the environment
+    dir::Env sw;
     float* splitk_scratch = nullptr;  // fp32 partial sums of split-K convs (inside the workspace)
     int prof_begin(const std::string& name, const std::string& kernel, double flops, double bytes,
                    hipStream_t stream);

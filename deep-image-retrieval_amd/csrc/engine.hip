@@ -25,6 +25,40 @@ int fail(int code, const std::string& msg) {
 const char* last_error() { return g_err.c_str(); }
 
 
+static Env read_env() {
+    Env e;
+    auto on = [](const char* k) { return getenv(k) != nullptr; };
+    const char* mode = getenv("DIRTORCH_AMD_C3C1");
+    e.c3c1_off = mode && mode[0] == '0';
+    e.c3c1_force = mode && mode[0] == 'f';
+    e.no_ds_seam = on("DIRTORCH_AMD_NO_DS_SEAM");
+    e.no_dual = on("DIRTORCH_AMD_NO_DUAL");
+    e.rev_conv1 = on("DIRTORCH_AMD_REV_CONV1");
+    e.rev_conv3 = on("DIRTORCH_AMD_REV_CONV3");
+    e.unfused_stem = on("DIRTORCH_AMD_UNFUSED_STEM");
+    e.stem_v1 = on("DIRTORCH_AMD_STEM_V1");
+    e.no_patchlc = on("DIRTORCH_AMD_NO_PATCHLC");
+    e.no_wreg = on("DIRTORCH_AMD_NO_WREG");
+    e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");
+    e.no_x3 = on("DIRTORCH_AMD_NO_X3");
+    e.no_patchs = on("DIRTORCH_AMD_NO_PATCHS");
+    e.no_xcdmap = on("DIRTORCH_AMD_NO_XCDMAP");
+    e.no_pair_patch = on("DIRTORCH_AMD_NO_PAIR_PATCH");
+    e.pair_acts = on("DIRTORCH_AMD_PAIR_ACTS");
+    if (const char* s = getenv("DIRTORCH_AMD_PAIR_STAGES")) e.pair_stages = atoi(s);
+    e.sim_v1 = on("DIRTORCH_AMD_SIM_V1");
+    e.sim_exact = on("DIRTORCH_AMD_SIM_EXACT");
+    e.experiments = on("DIRTORCH_AMD_EXPERIMENTS");
+    e.inplace = on("DIRTORCH_AMD_INPLACE");
+    return e;
+}
+static Env& env_slot() {
+    static Env e = read_env();   // (thread-safe first use)
+    return e;
+}
+const Env& env() { return env_slot(); }
+void reload_env() { env_slot() = read_env(); }   // host-driven (dir_reload_env): not concurrent with launches by contract
+
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // Deterministic noise in [-1, 1) for autotune inputs (no host RNG, no cuRAND analogue needed).
@@ -138,11 +172,10 @@ int dir_engine::finalize(int dt) {
     // DIRTORCH_AMD_PAIR_STAGES = 1..4 moves the boundary to the end of that stage.  Which weights: every conv of those
     // blocks with pair_acts (engine.h), else their 1x1s only.
     pair_blocks = 0;
-    pair_acts = !desc.bottleneck || getenv("DIRTORCH_AMD_PAIR_ACTS") != nullptr;
+    pair_acts = !desc.bottleneck || sw.pair_acts;
     std::vector<char> is_pair(convs.size(), 0);
     if (dt == DIR_FP16P) {
-        int stages = 1;
-        if (const char* env = getenv("DIRTORCH_AMD_PAIR_STAGES")) stages = atoi(env);
+        const int stages = sw.pair_stages;
         if (stages < 1 || stages > 4) return fail(DIR_ERR_INVALID, "finalize: DIRTORCH_AMD_PAIR_STAGES must be 1..4");
         for (int s = 0; s < stages; ++s) pair_blocks += desc.layers[s];
         if (x4_block >= 0 && pair_blocks > x4_block)
@@ -225,7 +258,8 @@ int dir_engine::finalize(int dt) {
             packed16[i] = to16(packed[i]);
             // fp16 saturates at 65504: a folded weight beyond that would become inf here, on the host, where no
             // kernel's overflow word can see it (and inf * 0 = NaN is then flushed to 0 by the next fused ReLU)
-            if (dt == DIR_FP16 && (packed16[i] & 0x7c00u) == 0x7c00u && std::isfinite(packed[i]))
+            // (DIR_FP16P packs the same fp16 hi plane: hi = inf would make lo = fp16(w - inf) = -inf and hi + lo = NaN)
+            if (dt != DIR_BF16 && (packed16[i] & 0x7c00u) == 0x7c00u && std::isfinite(packed[i]))
                 return fail(DIR_ERR_RANGE, "finalize: a BatchNorm-folded weight of " + L.name + " (" +
                                                std::to_string(packed[i]) + ") exceeds the fp16 range; use DIR_BF16 or DIR_F32");
         }
@@ -233,7 +267,11 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
         if (is_pair[li]) {   // lo plane: what the hi plane's rounding left over, itself rounded to fp16
             std::vector<uint16_t> lo16(packed.size());
-            for (size_t i = 0; i < packed.size(); ++i) lo16[i] = f32_to_f16_bits(packed[i] - f16_bits_to_f32(packed16[i]));
+            for (size_t i = 0; i < packed.size(); ++i) {
+                lo16[i] = f32_to_f16_bits(packed[i] - f16_bits_to_f32(packed16[i]));
+                if ((lo16[i] & 0x7c00u) == 0x7c00u && std::isfinite(packed[i]))   // (unreachable once hi is finite: |lo| <= ulp(hi) / 2)
+                    return fail(DIR_ERR_RANGE, "finalize: the lo plane of a paired weight of " + L.name + " is not finite");
+            }
             DIR_HIP_CHECK(hipMalloc((void**)&L.d_w_lo, lo16.size() * 2));
             DIR_HIP_CHECK(hipMemcpy(L.d_w_lo, lo16.data(), lo16.size() * 2, hipMemcpyHostToDevice));
             L.h_w_lo.swap(lo16);
@@ -753,7 +791,7 @@ int dir_engine::run_seam(ConvLayer& c3, ConvLayer& c1, const uint16_t* t2, const
         return DIR_OK;
     // (the layer3 form streams its weights per tile anyway: it only needs a few tiles per persistent workgroup)
     if (!sw.c3c1_force && (a.M + 63) / 64 < (a.Cin == 256 ? kSeam3MinTiles : kSeamMinTiles)) return DIR_OK;
-    if (a.Cin == 256 && sw.no_seam3) return DIR_OK;
+    if (a.Cin == 256 && !sw.experiments) return DIR_OK;   // conv_seam3.hip: experiments builds only (it loses: profiles/r04_seam3_ablation.txt)
     const double macs = (double)a.M * ((double)c3.Cout * (c3.Cin + a.Cin2) + (double)c1.Cout * c1.Cin);
     const double bytes = 2.0 * ((double)a.M * (c3.Cin + a.Cin2 * (block_in_lo ? 2 : 1) + (block_in ? 1.0 : 2.0) * c3.Cout + c1.Cout) +
                                 (double)c3.Cout * (c3.Cin + a.Cin2) * (a.w_lo ? 2 : 1) + (double)c1.Cout * c1.Cin * (a.w2_lo ? 2 : 1));
@@ -809,6 +847,8 @@ int dir_engine::run_conv_dual(ConvLayer& c3, const ConvLayer& ds, const uint16_t
     int rc = DIR_OK;
     if (profiling && !prof_paused)
         rc = prof_begin(c3.name.substr(0, c3.name.rfind('.')) + ".ds+conv3",
+                        // ("conv_igemm<VARIANT>" is the family label of every entry of the variant table; the variant name says
+                        // which kernel file runs it: 256x256_persist1x1_x3 = conv_persist.hip's deep-X ring, DUAL form)
                         std::string("conv_igemm<") + conv_variant(variant).name + "/dual>", 2.0 * macs, bytes, stream);
     if (rc != DIR_OK) return rc;
     rc = conv_launch(a, kdtype(), variant, stream);
@@ -826,20 +866,6 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
     if (cur_dev != device)   // the weights live on `device`; launching elsewhere would fault
         return fail(DIR_ERR_STATE, "forward: the current HIP device (" + std::to_string(cur_dev) +
                                        ") is not the engine's device (" + std::to_string(device) + ")");
-    {   // DIRTORCH_AMD_C3C1: "0" = never use the fused seam kernel, "force" = whenever the shapes qualify,
-        // default = when every persistent workgroup gets >= ~4 pixel tiles; the NO_* switches restore the
-        // separate downsample launch (A/B and bisecting; results equal up to 16-bit rounding)
-        const char* mode = getenv("DIRTORCH_AMD_C3C1");
-        sw.c3c1_off = mode && mode[0] == '0';
-        sw.c3c1_force = mode && mode[0] == 'f';
-        sw.no_ds_seam = getenv("DIRTORCH_AMD_NO_DS_SEAM") != nullptr;
-        sw.no_dual = getenv("DIRTORCH_AMD_NO_DUAL") != nullptr;
-        // conv_seam3.hip (layer3's conv3 -> conv1 in one kernel) is correct and tested but LOSES to the two kernels it
-        // replaces (245 vs 203 us at batch 32: profiles/r04_seam3_ablation.txt) - opt-in, for A/B: DIRTORCH_AMD_SEAM3=1
-        sw.no_seam3 = getenv("DIRTORCH_AMD_SEAM3") == nullptr;
-        sw.rev_conv1 = getenv("DIRTORCH_AMD_REV_CONV1") != nullptr;
-        sw.rev_conv3 = getenv("DIRTORCH_AMD_REV_CONV3") != nullptr;
-    }
     Plan p;
     int rc = plan(B, H, W, &p);
     if (rc != DIR_OK) return rc;
@@ -891,8 +917,7 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
             DIR_HIP_CHECK(hipGetLastError());
         }
         // 2. stem + maxpool: one kernel (stem_pool.hip) unless DIRTORCH_AMD_UNFUSED_STEM=1
-        static const bool unfused_stem = getenv("DIRTORCH_AMD_UNFUSED_STEM") != nullptr;
-        if (unfused_stem) {
+        if (sw.unfused_stem) {
             rc = run_conv(convs[0], s2d, nullptr, stem, B, p.H2, p.W2, p.OH1, p.OW1, stream);
             if (rc != DIR_OK) return rc;
             rc = prof_begin("maxpool", "maxpool_3x3s2", 0,

@@ -406,7 +406,7 @@ int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* ou
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_kernel, kLds, attr_done));
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_lc_kernel<false>, kLds, attr_done_lc));
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)sim_split_lc_kernel<true>, kLds2, attr_done_pair));
-    static const bool v1 = getenv("DIRTORCH_AMD_SIM_V1") != nullptr;   // A/B and bisecting: the one-role kernel (read once)
+    const bool v1 = env().sim_v1;   // A/B and bisecting: the one-role kernel
     const int T = K / 32, qblocks = ceil_div(NQ, kQB);
     if (unit_range && !v1) {   // operands in (-64, 64): two fp16 planes, three products
         hipLaunchKernelGGL(split_queries_kernel<true>, dim3(T, qblocks), dim3(256), 0, stream, Q, ldq, NQ, K, (uint16_t*)workspace);

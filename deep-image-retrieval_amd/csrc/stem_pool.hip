@@ -363,7 +363,7 @@ int stem_pool_launch(const void* s2d, const void* w, const float* bias, void* y,
     a.ovf = ovf;
     const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
     if (dtype != DIR_BF16 && dtype != DIR_FP16) return fail(DIR_ERR_INVALID, "stem_pool: bad dtype");
-    const bool v1 = getenv("DIRTORCH_AMD_STEM_V1") != nullptr;   // A/B and bisecting (read per launch: the tests flip it)
+    const bool v1 = env().stem_v1;   // A/B and bisecting (dir_reload_env after flipping it)
     if (!v1) {
         constexpr int LDSP = 2 * 2 * 512 * 16 + 8 * 32 * 128 + 256;   // two patch buffers + the conv tile + bias
         const long grid = blocks < 2L * cu_count() ? blocks : 2L * cu_count();

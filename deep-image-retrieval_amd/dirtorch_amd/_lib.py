@@ -63,6 +63,7 @@ SIGNATURES = {
     'dir_engine_profile_pause': (c_int, [c_void_p, c_int]),
     'dir_engine_get_profile': (c_int, [c_void_p, POINTER(ProfRecord), c_int, POINTER(c_int)]),
     'dir_conv_variant_count': (c_int, []),
+    'dir_reload_env': (c_int, []),
     'dir_conv_variant_name': (c_int, [c_int, c_char_p, c_int]),
     'dir_conv_bn_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14
                         + [c_void_p]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     'dir_stem_pool_pair': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     'dir_engine_overflow': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'dir_conv_heuristic': (c_int, [c_int] * 12 + [c_char_p, c_int, POINTER(c_int)]),
+    'dir_conv_variant_admissible': (c_int, [c_int] * 13 + [POINTER(c_int)]),
     'dir_conv_bn_act_splitk': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 15 +
                                [c_void_p, c_size_t, POINTER(c_int), c_void_p]),
     'dir_conv_c3c1': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -144,6 +146,13 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def reload_env():
+    """The library reads its DIRTORCH_AMD_* A/B switches from the environment once; after changing one inside a running
+    process (tests, A/B scripts) call this, then build a new engine.  No-op when the library has not been loaded yet."""
+    if _lib is not None:
+        _lib.dir_reload_env()
 
 
 def check(code):

@@ -81,9 +81,45 @@ def merge_score_blocks(score_blocks, n_total, w):
     return torch.cat([score_blocks[r, :, :h - l] for r, (l, h) in enumerate(shard_sizes(n_total, w))], dim=1).contiguous()
 
 
-def allgather_rows(local, n_total):
+def exchange_algo():
+    """How the one exchange step moves its blocks: 'rccl' = all_gather_into_tensor (RCCL picks ring / tree), 'mesh' = W - 1
+    direct point-to-point sends per rank in ONE grouped launch (every xGMI link of the GPU busy at once: SURVEY section 5 prices
+    the 8.2 GB exchange of configs[3] at ~6.7 ms that way against ~47 ms for a ring bound by one link).  DIRTORCH_AMD_EXCHANGE."""
+    algo = os.environ.get('DIRTORCH_AMD_EXCHANGE', 'rccl')
+    if algo not in ('rccl', 'mesh'):
+        raise ValueError("DIRTORCH_AMD_EXCHANGE must be 'rccl' or 'mesh', got %r" % algo)
+    return algo
+
+
+def allgather_blocks(out, block, algo=None):
+    """out[r * rows:(r + 1) * rows] = rank r's `block` ([rows, ...], equal shapes on every rank), on every rank.  ONE exchange
+    step either way: algo 'rccl' - the collective; 'mesh' - a full-mesh of direct sends / receives issued as one group
+    (batch_isend_irecv: ncclGroupStart ... ncclSend / ncclRecv ... ncclGroupEnd under RCCL, so all W - 1 peers move at once)."""
+    w, r = world_size(), rank()
+    rows = block.shape[0]
+    assert out.shape[0] == w * rows and out.shape[1:] == block.shape[1:], (out.shape, block.shape, w)
+    algo = exchange_algo() if algo is None else algo
+    if w == 1:
+        out.copy_(block)
+    elif algo == 'mesh':
+        out[r * rows:(r + 1) * rows].copy_(block)
+        ops = []
+        for d in range(1, w):            # peer order staggered per rank: step d pairs r -> r + d with r - d -> r
+            to, frm = (r + d) % w, (r - d) % w
+            ops.append(torch.distributed.P2POp(torch.distributed.isend, block, to))
+            ops.append(torch.distributed.P2POp(torch.distributed.irecv, out[frm * rows:(frm + 1) * rows], frm))
+        for req in torch.distributed.batch_isend_irecv(ops):
+            req.wait()
+    elif block.is_cuda:
+        torch.distributed.all_gather_into_tensor(out, block)
+    else:
+        torch.distributed.all_gather([out[i * rows:(i + 1) * rows] for i in range(w)], block)
+    return out
+
+
+def allgather_rows(local, n_total, algo=None):
     """local: this rank's [hi-lo, D] block (rows shard_range(n_total)) -> the full [n_total, D]
-    on every rank, in dataset order.  One collective."""
+    on every rank, in dataset order.  One collective (or one group of direct sends: allgather_blocks)."""
     w = world_size()
     if w == 1:
         assert local.shape[0] == n_total
@@ -95,14 +131,8 @@ def allgather_rows(local, n_total):
     D = local.shape[1]
     padded = local.new_zeros((rows, D))
     padded[:hi - lo] = local
-    if local.is_cuda:
-        out = local.new_empty((w * rows, D))
-        torch.distributed.all_gather_into_tensor(out, padded.contiguous())
-        parts = [out[r * rows:r * rows + (h - l)] for r, (l, h) in enumerate(sizes)]
-    else:
-        bufs = [local.new_empty((rows, D)) for _ in range(w)]
-        torch.distributed.all_gather(bufs, padded.contiguous())
-        parts = [bufs[r][:h - l] for r, (l, h) in enumerate(sizes)]
+    out = allgather_blocks(local.new_empty((w * rows, D)), padded.contiguous(), algo)
+    parts = [out[r * rows:r * rows + (h - l)] for r, (l, h) in enumerate(sizes)]
     return torch.cat(parts, dim=0)
 
 

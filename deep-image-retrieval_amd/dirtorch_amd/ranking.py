@@ -27,15 +27,31 @@ def is_unit_range(*tensors):
     return True
 
 
+_RANGE_CACHE = {}     # (data_ptr, shape, dtype, _version) of a database tensor -> is_unit_range verdict (a few entries)
+
+
+def database_is_unit_range(b):
+    """is_unit_range(b), remembered per database TENSOR: the full pass over an 8 GB database (1.5 ms + a host sync) is paid
+    once, not on every query batch - the key carries the tensor's version counter, so an in-place update re-checks."""
+    key = (b.data_ptr(), tuple(b.shape), b.dtype, b._version)
+    hit = _RANGE_CACHE.get(key)
+    if hit is None:
+        if len(_RANGE_CACHE) >= 8:
+            _RANGE_CACHE.clear()
+        hit = _RANGE_CACHE[key] = is_unit_range(b)
+    return hit
+
+
 def similarity_device(qdescs, bdescs, unit_range=None):
     """Scores Q.DB^T as a CUDA tensor [Q, N] (common.matmul without the download).  unit_range: True = the caller knows
     both sets are bounded by 60 in magnitude (L2-normalised descriptors: dirtorch/test_dir.py:150) and wants the fp16-pair
-    kernel on large databases (ops.similarity); None (default) = look (is_unit_range: 1.5 ms per 10^6 x 2048 rows) when the
-    database is large enough for it to matter; False = never."""
+    kernel on large databases (ops.similarity); None (default) = look, when the database is large enough for it to matter -
+    the DATABASE's verdict is cached per tensor (database_is_unit_range), only the small query block is checked per call;
+    False = never.  Evaluation loops that know their descriptors are L2-normalised pass True."""
     from .utils.common import _dev
     q, b = _dev(qdescs), _dev(bdescs)
     if unit_range is None:
-        unit_range = b.shape[0] >= UNIT_RANGE_MIN_ROWS and is_unit_range(q, b)
+        unit_range = b.shape[0] >= UNIT_RANGE_MIN_ROWS and database_is_unit_range(b) and is_unit_range(q)
     return ops.similarity(q, b, unit_range=bool(unit_range))
 
 

@@ -104,6 +104,11 @@ typedef struct dir_engine dir_engine;
 const char* dir_last_error(void);
 /* "dir_engine <version> gfx950" — lets the host check it loaded the library it expects. */
 const char* dir_version(void);
+/* The DIRTORCH_AMD_* A/B switches (kernel-selection toggles for bisecting; no reference counterpart - the reference reads no
+ * environment on this path) are read from the environment ONCE, at the library's first use, and copied into an engine at
+ * dir_engine_create.  A host that changes one of them afterwards (tests, A/B scripts) calls this to re-read them; engines
+ * created later see the new values.  Not to be called concurrently with launches. */
+int dir_reload_env(void);
 
 /* ---- model life cycle: replaces nets.create_model + net.load_state_dict + net.cuda() ------- */
 /* dirtorch/nets/__init__.py:24-64, dirtorch/test_dir.py:183-191 */
@@ -210,6 +215,11 @@ int dir_conv_bn_act(const void* x, const void* w, const float* bias, const void*
  * CPU tests (tests/test_capi_host.py). */
 int dir_conv_heuristic(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int OH,
                        int OW, int has_residual, char* name, int cap, int* ksplit);
+/* Would dir_conv_bn_act accept `variant` for this shape?  *admissible = 1 / 0.  Pure host logic (the predicate conv_launch
+ * itself applies), exposed so that the GPU parity matrix is generated from admissible (variant, shape) pairs only and the
+ * tests' own mirror of the rule is pinned on the CPU (tests/test_capi_host.py). */
+int dir_conv_variant_admissible(int variant, int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad,
+                                int OH, int OW, int has_residual, int* admissible);
 /* Same convolution with the K loop cut into `ksplit` slices that run as separate workgroups and meet in
  * an fp32 scratch buffer (ksplit * B*OH*OW * Cout floats; slices are added in a fixed order, then bias /
  * residual / ReLU) - what the engine does for layers with too few output tiles to fill 256 CUs (batch 1

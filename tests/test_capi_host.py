@@ -28,6 +28,33 @@ def test_library_exports_every_declared_symbol():
     assert lib.dir_conv_variant_count() >= 4
 
 
+def test_gpu_parity_matrix_mirror_of_the_admissibility_rule():
+    """tests/test_ops_gpu.py generates its (shape, variant) matrix from its own mirror of conv_variant_admissible; the
+    library's predicate (dir_conv_variant_admissible, host-only) must agree on every pair, so that no admissible pair goes
+    untested and no inadmissible one is launched.  The default library ships no experiments kernel."""
+    import ctypes
+    import importlib.util
+    from dirtorch_amd import _lib, ops
+    spec = importlib.util.spec_from_file_location('ops_gpu_matrix', os.path.join(ROOT, 'tests', 'test_ops_gpu.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    names = ops.conv_variant_names()
+    if 'DIRTORCH_AMD_LIB' not in os.environ:
+        assert '128x256_ring1x1' not in names
+    ok = ctypes.c_int()
+    n_adm = 0
+    for s in m.CONV_SHAPES:
+        _, B, H, W, Cin, Cout, k, stride, pad, use_res, _ = s
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        for v, name in enumerate(names):
+            _lib.call('dir_conv_variant_admissible', v, B, H, W, Cin, Cout, k, k, stride, pad, OH, OW, int(use_res), ctypes.byref(ok))
+            assert bool(ok.value) == m.variant_admissible(name, Cin, Cout, k, stride, pad, use_res), (s[0], name, ok.value)
+            n_adm += ok.value
+    assert n_adm == len(m.CONV_CASES) and n_adm > 100
+    with pytest.raises(_lib.DirError):
+        _lib.call('dir_conv_variant_admissible', len(names), 1, 8, 8, 64, 64, 1, 1, 1, 0, 8, 8, 0, ctypes.byref(ok))
+
+
 def test_argument_errors_do_not_need_a_gpu():
     from dirtorch_amd import _lib
     lib = _lib.load()

@@ -189,6 +189,7 @@ def _worker(rank, world, port, ns, out):
     for n in ns:
         lo, hi = dd.shard_range(n)
         res[('gather', n)] = dd.allgather_rows(_fake_descs(lo, hi), n)
+        res[('mesh', n)] = dd.allgather_rows(_fake_descs(lo, hi), n, algo='mesh')   # W - 1 direct sends, one group
         res[('extract', n)] = dd.extract_sharded(_fake_extract, _FakeDB(n), '', _FakeNet())
     # a failure on ONE rank's shard (fp16 overflow, test_dir._check_finite) must surface on EVERY rank before
     # the collective, not leave the healthy ranks blocked in it
@@ -219,9 +220,32 @@ def test_allgather_equals_single_process_concat_gloo_ws2():
         full = _fake_descs(0, n)
         for r in (0, 1):
             assert torch.equal(res[r][('gather', n)], full), (n, r)       # bit-for-bit
+            assert torch.equal(res[r][('mesh', n)], full), (n, r)         # the full-mesh exchange: the same rows
             assert torch.equal(res[r][('extract', n)], full), (n, r)
     assert 'fp16 overflow inside the trunk' in res[0]['overflow'] and 'another rank' in res[1]['overflow'], \
         (res[0]['overflow'], res[1]['overflow'])
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_launches_itself_without_torchrun():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment becomes its own launcher (N ranks, rendezvous on
+    127.0.0.1, rank 0 prints the one line); --dry-launch runs that plumbing and the path's one exchange step over gloo on
+    the CPU.  Without GPUs the real run refuses with the counts, not with a usage error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    for extra in ([], ['--workload', 'distractors']):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-launch'] + extra, env=env,
+                           capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+        assert line['ranks'] == 2 and line['n_gpus'] == 2 and line['exchange_ok'] is True
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                           text=True, timeout=240)
+        assert r.returncode != 0 and 'needs 2 GPUs, found' in r.stderr, (r.returncode, r.stderr[-500:])
 
 
 def test_single_process_passthrough():

@@ -100,11 +100,14 @@ def test_pair_conv_vs_torch_fp32(geom):
     if k == 3 and Cin == 64 and Cout == 64 and not with_res:
         # the patch-pair kernel (default for this shape) against the implicit-GEMM form of the same convolution
         import os
+        from dirtorch_amd import _lib
         os.environ['DIRTORCH_AMD_NO_PAIR_PATCH'] = '1'
+        _lib.reload_env()
         try:
             yi = ops.conv_bn_act_pair(xp, wp, bias.cuda(), rp, stride=stride, pad=pad, relu=relu)
         finally:
             del os.environ['DIRTORCH_AMD_NO_PAIR_PATCH']
+            _lib.reload_env()
         assert float((join(yi) - join(y)).abs().max()) < 4e-6 * scale
     # zero padding / ragged-tile masks: an all-zero input gives relu(bias (+ res)) to pair precision
     z = ops.conv_bn_act_pair((torch.zeros_like(xp[0]), torch.zeros_like(xp[1])), wp, bias.cuda(), rp, stride=stride,
@@ -272,11 +275,14 @@ def test_stem_pool_pair_vs_torch_fp32(B, H, W):
     assert float((got - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max()))
     # the one-tile-per-workgroup form (DIRTORCH_AMD_STEM_V1) computes the same sums in the same order
     import os
+    from dirtorch_amd import _lib
     os.environ['DIRTORCH_AMD_STEM_V1'] = '1'
+    _lib.reload_env()
     try:
         y1 = ops.stem_pool_pair(s2d, wp, bias.cuda(), (OH, OW))
     finally:
         del os.environ['DIRTORCH_AMD_STEM_V1']
+        _lib.reload_env()
     assert torch.equal(y1[0], y[0]) and torch.equal(y1[1], y[1])
     # the fp16 stem of the same image differs from it at the fp16 level: the test can tell the two apart
     single = ops.stem_pool(s2d[0], wp[0], bias.cuda(), (OH, OW)).float().cpu().double()
