@@ -42,6 +42,7 @@ static Env read_env() {
     e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");
     e.no_x3 = on("DIRTORCH_AMD_NO_X3");
     e.no_patchs = on("DIRTORCH_AMD_NO_PATCHS");
+    e.no_patchw_lc = on("DIRTORCH_AMD_NO_PATCHW_LC");
     e.no_xcdmap = on("DIRTORCH_AMD_NO_XCDMAP");
     e.no_pair_patch = on("DIRTORCH_AMD_NO_PAIR_PATCH");
     e.pair_acts = on("DIRTORCH_AMD_PAIR_ACTS");
@@ -950,6 +951,12 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
         const bool keep = (int)bi == x4_block;
         nxt = keep ? (uint16_t*)(base + p.x4) : (cur == pp[0] ? pp[1] : pp[0]);
+        // DIRTORCH_AMD_INPLACE (round-5 probe, profiles/r05_mall_probe.txt): the identity blocks of layers 3-4 write their
+        // output OVER their input - conv3 reads every residual element it adds before it stores that element (conv_wreg: one
+        // strip ahead in registers; conv_persist / the tiled kernels: the whole tile before the K loop), and no other
+        // workgroup touches it - so that a sub-batch's map + t1 + t2 (12.6 MB per image in layer3) can stay in the 256 MiB
+        // Infinity Cache.  Bit-identical results.
+        if (sw.inplace && desc.bottleneck && bd.down < 0 && !keep && !tuning && convs[bd.conv3].Cin >= 256) nxt = cur;
         const uint16_t* resid = cur;
         // layer1's first block: the downsample can ride in the seam kernel as extra K (conv_c3c1.hip, DS
         // form) - only if that kernel will actually run for this shape, decided before anything launches

@@ -550,6 +550,37 @@ def test_ring_kernel_at_scale(B, HW, Cin, Cout, stride):
         assert torch.equal(got, again), dname
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,res', [(32, 64, 64, 256, 256, False), (8, 128, 128, 128, 128, False), (16, 32, 32, 512, 512, False),
+                                                 (3, 37, 33, 128, 256, True), (2, 13, 70, 64, 128, False), (5, 64, 64, 256, 256, True)],
+                         ids=['layer3.conv2_b32', 'layer2.conv2', 'layer4.conv2', 'ragged_res', 'ragged_k64', 'odd_batch_res'])
+def test_patchw_loader_consumer_form_is_bit_identical(B, H, W, Cin, Cout, res, monkeypatch):
+    """conv_patchw.hip's loader / consumer form (round 5, the default: twelve waves, waves 8-11 only issue LDS-DMA, waves 0-7
+    only read fragments and multiply) against the one-role kernel it replaces (DIRTORCH_AMD_NO_PATCHW_LC): the same stages,
+    fragments and MFMA order per accumulator - bit for bit, at network scale (two tiles per CU, ragged tiles, residual), run to
+    run, and element by element against the naive device checker."""
+    ops = _ops()
+    v = ops.conv_variant_names().index('512x128_patch3x3w')
+    for dname, dt in DTYPES.items():
+        g = torch.Generator(device='cuda').manual_seed(61)
+        x = torch.relu(torch.randn(B, H, W, Cin, generator=g, device='cuda')).to(dt)
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g, device='cuda') * (2.0 / (9 * Cin)) ** 0.5).to(dt)
+        bias = torch.randn(Cout, generator=g, device='cuda') * 0.1
+        r = torch.randn(B, H, W, Cout, generator=g, device='cuda').to(dt) if res else None
+        kw = dict(stride=1, pad=1, relu=True)
+        monkeypatch.delenv('DIRTORCH_AMD_NO_PATCHW_LC', raising=False)
+        lc = ops.conv_bn_act(x, w, bias, r, variant=v, **kw)
+        again = ops.conv_bn_act(x, w, bias, r, variant=v, **kw)
+        monkeypatch.setenv('DIRTORCH_AMD_NO_PATCHW_LC', '1')
+        one = ops.conv_bn_act(x, w, bias, r, variant=v, **kw)
+        monkeypatch.delenv('DIRTORCH_AMD_NO_PATCHW_LC')
+        assert torch.equal(lc, one), dname
+        assert torch.equal(lc, again), dname
+        ref = ops.conv_bn_act(x, w, bias, r, naive=True, **kw).float()
+        err = (lc.float() - ref).abs()
+        tol = RTOL[dname] * ref.abs() + RTOL[dname] * ref.abs().mean()
+        assert int((err > tol).sum()) == 0, (dname, float(err.max()))
+
+
 @pytest.mark.parametrize('shape', [(63, 128, 128, 512), (8, 128, 128, 512), (8, 64, 256, 1024)],
                          ids=lambda s: 'B%d_%d_K%d_N%d' % s)
 def test_wreg_persistent_kernel_first_tiles_at_scale(shape):
