@@ -21,6 +21,12 @@
 #include "conv_igemm.h"
 #include "pointwise.h"
 
+// Timing-only experiment builds of stem_pool_pair_persist_kernel (scripts/exp_abl.sh conv_pair DIR_STEMP_ABL <bits>): 1 = no MFMAs /
+// fragment reads, 2 = no pooling phase (conv tile written, never read; no stores), 4 = no patch DMA.  NOT valid results.
+#ifndef DIR_STEMP_ABL
+#define DIR_STEMP_ABL 0
+#endif
+
 namespace dir {
 
 static constexpr uint32_t kOOBp = 0x80000000u;
@@ -856,6 +862,7 @@ __global__ void __launch_bounds__(512) stem_pool_pair_persist_kernel(const StemP
             const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
             const bool ok = p < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
             const uint32_t v = ok ? (uint32_t)((((b * a.H2 + iy) * a.W2 + ix) * 16 + plane * 8) * 2) : kOOBp;
+            if (DIR_STEMP_ABL & 4) continue;   // (experiment: no patch DMA)
             dma16p(rsrc_xh, dst + (i * 512 + wave * 64) * 16, v, 0);
             dma16p(rsrc_xl, dst + PATCH + (i * 512 + wave * 64) * 16, v, 0);
         }
@@ -909,6 +916,7 @@ __global__ void __launch_bounds__(512) stem_pool_pair_persist_kernel(const StemP
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (DIR_STEMP_ABL & 1) continue;   // (experiment: no MFMAs, no fragment reads)
                     acc[j] = DT::mfma32(wfh[R][ks], xh[j], acc[j]);
                     acc[j] = DT::mfma32(wfh[R][ks], xl[j], acc[j]);
                     acc[j] = DT::mfma32(wfl[R][ks], xh[j], acc[j]);
@@ -943,7 +951,7 @@ __global__ void __launch_bounds__(512) stem_pool_pair_persist_kernel(const StemP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ring_barrier();   // conv tile complete; every wave is past its patch reads
 
-        for (int it = tid; it < PTH * PTW * 8; it += 512) {
+        for (int it = tid; it < ((DIR_STEMP_ABL & 2) ? 0 : PTH * PTW * 8); it += 512) {   // (experiment bit 2: no pooling phase)
             const int c8 = it & 7;
             const int pp = it >> 3;
             const int py = pp / PTW, px = pp - py * PTW;
