@@ -282,6 +282,8 @@ __global__ void __launch_bounds__(512) conv_patch3x3w_kernel(const ConvArgs a) {
 // reads and MFMA order here - bit-identical results - with the work split by wave role: TWELVE waves, waves 0-7 only read
 // fragments and multiply (two per SIMD), waves 8-11 only issue LDS-DMA and wait for it (one per SIMD; 10 instructions per plane
 // and 6 per weight stage each, a counted vmcnt over one kind of op).  One barrier per stage is the hand-off in both directions.
+// (s_setprio on either role - consumers 1 / 3, loaders 1 - measured: 14.11-14.18 ms per step in every combination, 14.13-14.15
+// without; not kept.)
 // Twelve waves = three per SIMD = 168 VGPRs per wave: the consumers' 128 accumulator registers leave 40, so fragments are
 // fetched one K half (kk) at a time.
 template <class DT>
