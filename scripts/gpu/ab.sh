@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of ONE environment switch on one box: bench.py with and without "$1" (e.g. DIRTORCH_AMD_SEAM3=1), twice each,
+# A/B of ONE environment switch on one box: bench.py with and without "$1" (e.g. DIRTORCH_AMD_NO_PATCHW_LC=1), twice each,
 # interleaved; then the per-layer times of both legs for the layers matching $2 (default conv2).  $3 = output tag,
 # BENCH_ARGS = extra bench.py flags (e.g. "--dtype fp16p").  How every kernel of rounds 2-4 was accepted or dropped.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"

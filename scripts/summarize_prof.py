@@ -84,7 +84,7 @@ def short(name):
     m = re.search(r'conv_patch3x3s_kernel<dir::(\w+), (\d+)>', name)
     if m:
         return 'conv_igemm<256x256_patch3x3s>[%s]' % m.group(1).lower()
-    m = re.search(r'conv_patch3x3w_kernel<dir::(\w+)>', name)
+    m = re.search(r'conv_patch3x3w(?:_lc)?_kernel<dir::(\w+)>', name)   # (one-role form and, round 5, the loader / consumer form)
     if m:
         return 'conv_igemm<512x128_patch3x3w>[%s]' % m.group(1).lower()
     m = re.search(r'conv_patch3x3_kernel<dir::(\w+), (\d+), (\d+)', name)

@@ -375,11 +375,12 @@ def test_fp16p_plumbing(monkeypatch):
     assert sum(k.startswith('conv_igemm<') for k in kernels[:12]) == 3, kernels
     # ... and with the seam kernels forced (what batch 32 at 1024^2 runs): paired weights inside conv_c3c1.hip
     monkeypatch.setenv('DIRTORCH_AMD_C3C1', 'force')
-    net = make_net('resnet50', sd)       # (an engine copies the A/B switches when it is created: dir_reload_env + a new engine)
-    net.set_profiling(True)
-    bs = net(xf.cuda()).cpu()
-    kernels = [r['kernel'] for r in net.get_profile()]
-    net.set_profiling(False)
+    netf = make_net('resnet50', sd)      # (an engine copies the A/B switches when it is created: dir_reload_env + a new engine)
+    netf.set_profiling(True)
+    bs = netf(xf.cuda()).cpu()
+    kernels = [r['kernel'] for r in netf.get_profile()]
+    netf.set_profiling(False)
+    del netf
     monkeypatch.delenv('DIRTORCH_AMD_C3C1')
     assert kernels[:8] == ['prep_input_pair', 'stem_pool_pair', 'conv_pair<128x64_xw>', kernels[3], 'conv_c3c1<64,ds,wp>',
                            kernels[5], 'conv_c3c1<64,wp>', kernels[7]] and kernels[8] == 'conv_c3c1<64,wp>', kernels
