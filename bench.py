@@ -597,10 +597,19 @@ def self_spawn(n, argv, dry=False):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for pr in procs:
-        code = pr.wait()
-        rc = rc or code
+    # wait for all ranks; when one fails, the others would sit in a collective forever: stop exactly the processes started here
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:
+                    other.terminate()
     return rc
 
 
