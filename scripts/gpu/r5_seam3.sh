@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: (1) the layer3 seam with dedicated storer waves (conv_seam3.hip, experiments build): op-level parity, standalone timing against
+# round 5: (1) the layer3 seam (conv_seam3.hip, experiments build; with profiles/r05_seam3_storers.patch applied: its storer-wave form): op-level parity, standalone timing against
 # the two launches it replaces, the whole step with it; (2) the Winograd pricing builds of conv_patchw.hip (scripts/exp_abl.sh
 # conv_patchw DIR_PATCHW_ABL 8 24 56) on the 3x3 shapes.      gpurun -- 'bash scripts/gpu/r5_seam3.sh <tag>'
 TAG=${1:-r5seam3}
