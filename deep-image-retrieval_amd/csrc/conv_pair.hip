@@ -921,6 +921,8 @@ __global__ void __launch_bounds__(512) stem_pool_pair_persist_kernel(const StemP
                     acc[j] = DT::mfma32(wfh[R][ks], xl[j], acc[j]);
                     acc[j] = DT::mfma32(wfl[R][ks], xh[j], acc[j]);
                 }
+                // (issue order measured - weight fragment held over both rows with alternating accumulators, or the pixel
+                // fragment held: 981-999 / 983-994 / 994-1009 us - no effect here: gpurun_out/r5stemorder)
             }
 
         int wg = tile;

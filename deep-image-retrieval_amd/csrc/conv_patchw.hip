@@ -427,10 +427,15 @@ __global__ void __launch_bounds__(768) conv_patch3x3w_lc_kernel(const ConvArgs a
                 }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) wf[i] = *(const frag_t*)(wst + s * (BN * 64) + i * 2048 + woffk[kk]);
+                // Issue order: the PIXEL fragment is held over four consecutive MFMAs while the weight fragment changes (j outer, i
+                // inner - and written so, because hipcc's own schedule of the i-outer loop interleaved them irregularly).  The kernel
+                // is power-bound (MfmaUtil x clock is constant across its forms); which operand toggles between consecutive
+                // MFMAs is worth 2-3 % of the launch: 126.5 -> 123.5 us in layer3, 117.5 -> 113.5 us in layer4, step 14.14 -> 14.07 ms
+                // (A/B, three orders, profiles/r05_patchw_phases.txt).  Per accumulator the k order is unchanged: bit-identical.
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                for (int j = 0; j < TMR; ++j)
 #pragma unroll
-                    for (int j = 0; j < TMR; ++j) acc[i][j] = DT::mfma32(wf[i], xf[j], acc[i][j]);
+                    for (int i = 0; i < TN; ++i) acc[i][j] = DT::mfma32(wf[i], xf[j], acc[i][j]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's LDS reads retired before the next barrier
