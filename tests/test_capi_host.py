@@ -55,6 +55,34 @@ def test_gpu_parity_matrix_mirror_of_the_admissibility_rule():
         _lib.call('dir_conv_variant_admissible', len(names), 1, 8, 8, 64, 64, 1, 1, 1, 0, 8, 8, 0, ctypes.byref(ok))
 
 
+def test_switches_are_read_once_and_reloaded_on_request():
+    """The DIRTORCH_AMD_* A/B switches are read from the environment ONCE (no getenv on any launch path); dir_reload_env
+    re-reads them.  Observed through the host-only heuristic query: layer3's 3x3 takes the 512 x 128 patch kernel unless
+    DIRTORCH_AMD_NO_PATCHW is set - and setting it has no effect until the reload."""
+    import ctypes
+    from dirtorch_amd import _lib
+    lib = _lib.load()
+
+    def pick():
+        buf, ks = ctypes.create_string_buffer(64), ctypes.c_int()
+        _lib.call('dir_conv_heuristic', 32, 64, 64, 256, 256, 3, 3, 1, 1, 64, 64, 0, buf, 64, ctypes.byref(ks))
+        return buf.value.decode()
+    saved = os.environ.pop('DIRTORCH_AMD_NO_PATCHW', None)
+    try:
+        assert lib.dir_reload_env() == 0
+        assert pick() == '512x128_patch3x3w'
+        os.environ['DIRTORCH_AMD_NO_PATCHW'] = '1'
+        assert pick() == '512x128_patch3x3w'          # not re-read behind the host's back
+        _lib.reload_env()
+        assert pick() != '512x128_patch3x3w'
+    finally:
+        os.environ.pop('DIRTORCH_AMD_NO_PATCHW', None)
+        if saved is not None:
+            os.environ['DIRTORCH_AMD_NO_PATCHW'] = saved
+        _lib.reload_env()
+    assert pick() == '512x128_patch3x3w'
+
+
 def test_argument_errors_do_not_need_a_gpu():
     from dirtorch_amd import _lib
     lib = _lib.load()
