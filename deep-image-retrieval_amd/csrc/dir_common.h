@@ -51,7 +51,7 @@ struct Env {
     int pair_stages = 1;                         // ..._PAIR_STAGES = 1..4 (validated at finalize)
     bool sim_v1 = false, sim_exact = false;      // ..._SIM_V1 (one-role kernel), ..._SIM_EXACT (fp32 MFMA chain at any size)
     bool experiments = false;                    // ..._EXPERIMENTS: opt-in kernels of an experiments build (conv_ring / conv_seam3)
-    bool inplace = false;                        // ..._INPLACE: conv3 writes the block output over the block input (round-5 probe)
+    bool no_inplace = false;                     // ..._NO_INPLACE: layers 3-4's identity blocks ping-pong again instead of writing their output in place
 };
 const Env& env();
 void reload_env();

@@ -50,7 +50,7 @@ static Env read_env() {
     e.sim_v1 = on("DIRTORCH_AMD_SIM_V1");
     e.sim_exact = on("DIRTORCH_AMD_SIM_EXACT");
     e.experiments = on("DIRTORCH_AMD_EXPERIMENTS");
-    e.inplace = on("DIRTORCH_AMD_INPLACE");
+    e.no_inplace = on("DIRTORCH_AMD_NO_INPLACE");
     return e;
 }
 static Env& env_slot() {
@@ -951,12 +951,14 @@ int dir_engine::forward(const void* img, int B, int H, int W, int fmt, float* de
         const int oh = conv_out(h, 3, bd.stride, 1), ow = conv_out(w, 3, bd.stride, 1);
         const bool keep = (int)bi == x4_block;
         nxt = keep ? (uint16_t*)(base + p.x4) : (cur == pp[0] ? pp[1] : pp[0]);
-        // DIRTORCH_AMD_INPLACE (round-5 probe, profiles/r05_mall_probe.txt): the identity blocks of layers 3-4 write their
-        // output OVER their input - conv3 reads every residual element it adds before it stores that element (conv_wreg: one
-        // strip ahead in registers; conv_persist / the tiled kernels: the whole tile before the K loop), and no other
-        // workgroup touches it - so that a sub-batch's map + t1 + t2 (12.6 MB per image in layer3) can stay in the 256 MiB
-        // Infinity Cache.  Bit-identical results.
-        if (sw.inplace && desc.bottleneck && bd.down < 0 && !keep && !tuning && convs[bd.conv3].Cin >= 256) nxt = cur;
+        // The identity blocks of layers 3-4 write their output OVER their input (round 5; DIRTORCH_AMD_NO_INPLACE restores the
+        // ping-pong).  Safe and bit-identical: conv3 reads every residual element it adds before it stores that element - conv_wreg
+        // one strip ahead in registers, conv_persist / the tiled kernels the whole tile before the K loop, the split-K finalize
+        // element by element - and no other workgroup touches it (conv3's INPUT is t2).  Found while pricing Infinity-Cache
+        // residency (profiles/r05_mall_probe.txt: the cache itself buys nothing), kept for what it does in HBM: a
+        // read-modify-write stream gets 5.6-5.9 TB/s where a copy gets 5.2-5.4 - layer3's conv3 110 -> 104 us, step 14.03 -> 13.96 ms
+        // (A/B on one box) - and layer3's footprint in the workspace halves.
+        if (!sw.no_inplace && desc.bottleneck && bd.down < 0 && !keep && !tuning && convs[bd.conv3].Cin >= 256) nxt = cur;
         const uint16_t* resid = cur;
         // layer1's first block: the downsample can ride in the seam kernel as extra K (conv_c3c1.hip, DS
         // form) - only if that kernel will actually run for this shape, decided before anything launches

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Round-5 probe: do the identity blocks of layers 3-4 run faster when a sub-batch's tensors fit the
 256 MiB Infinity Cache?  Runs the bench network (R101 @ 1024^2, fp16p) at batch 8 / 16 / 32 with the block outputs
-ping-ponging (default) and IN PLACE (DIRTORCH_AMD_INPLACE=1: map + t1 + t2 = 12.6 MB per image in layer3 -> 201 MB at
+ping-ponging (DIRTORCH_AMD_NO_INPLACE=1) and IN PLACE (the default since the end of round 5: map + t1 + t2 = 12.6 MB per image in layer3 -> 201 MB at
 batch 16), prints the layer3 / layer4 per-launch times of both forms and checks the descriptors are bit-identical."""
 import json
 import os
@@ -16,10 +16,10 @@ from dirtorch_amd import _lib, nets  # noqa: E402
 
 
 def run(B, inplace, steps=12):
-    if inplace:
-        os.environ['DIRTORCH_AMD_INPLACE'] = '1'
+    if inplace:          # (the default since the end of round 5)
+        os.environ.pop('DIRTORCH_AMD_NO_INPLACE', None)
     else:
-        os.environ.pop('DIRTORCH_AMD_INPLACE', None)
+        os.environ['DIRTORCH_AMD_NO_INPLACE'] = '1'
     _lib.load()
     _lib.reload_env()
     net = nets.create_model('resnet101_rmac', pretrained='')

@@ -304,3 +304,30 @@ def test_fused_seams_inside_the_network(monkeypatch):
     d_plain = make_net('resnet50', {}, sd, 'bf16')(x[:2, :256, :256].contiguous())
     assert np.all(1 - O.cosine(d_forced.cpu().numpy(), d_plain.cpu().numpy()) < 1e-5)
 
+
+
+@pytest.mark.parametrize('arch,B,H,W,dtype', [('resnet101', 1, 500, 375, 'fp16p'), ('resnet50', 8, 512, 512, 'bf16'),
+                                             ('resnet101', 4, 1024, 1024, 'fp16'), ('resnet50', 3, 224, 224, 'fp16p'),
+                                             ('resnet101', 1, 1024, 768, 'bf16')],
+                         ids=['r101_b1_odd_splitk', 'r50_b8_512', 'r101_b4_1024', 'r50_b3_224', 'r101_b1_1024x768'])
+def test_in_place_identity_blocks_are_bit_identical(arch, B, H, W, dtype, monkeypatch):
+    """Since round 5 the identity blocks of layers 3-4 write their output over their input (engine.hip: every conv3 kernel
+    reads the residual element it adds before it stores that element).  The descriptors and the trunk map must equal the
+    ping-pong form's (DIRTORCH_AMD_NO_INPLACE) bit for bit - at batch 1 (split-K finalize, small tiles), at odd sizes (ragged
+    tiles) and at the batched sizes where the register-stationary / persistent kernels run - and the FPN head, which keeps
+    layer3's output, is unaffected."""
+    import dir_oracle as O
+    sd = O.synth_state_dict(arch, seed=7)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8, device='cuda')
+    monkeypatch.delenv('DIRTORCH_AMD_NO_INPLACE', raising=False)
+    net = make_net(arch, {}, sd, dtype)
+    d_in, f_in = net(x).clone(), net.forward_features(x).clone()
+    net.set_profiling(True)
+    net(x)
+    kernels = {r['kernel'] for r in net.get_profile()}
+    monkeypatch.setenv('DIRTORCH_AMD_NO_INPLACE', '1')
+    ref = make_net(arch, {}, sd, dtype)
+    d_pp, f_pp = ref(x), ref.forward_features(x)
+    assert torch.equal(d_in, d_pp) and torch.equal(f_in, f_pp), (arch, B, H, W, dtype, sorted(kernels))
+    assert torch.isfinite(d_in).all()
