@@ -26,12 +26,14 @@ def world_size():
     return torch.distributed.get_world_size() if is_initialized() else 1
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run);
-    no-op for a single process.  Returns (rank, world, local_rank)."""
+    no-op for a single process unless `force` (a one-rank group: the same RCCL communicator set-up, buffer
+    registration and collectives as on N GPUs - how the exchange step is exercised on a one-GPU box).
+    Returns (rank, world, local_rank)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not is_initialized():
+    if (world > 1 or (force and 'RANK' in os.environ)) and not is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this driver
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -99,7 +101,7 @@ def allgather_blocks(out, block, algo=None):
     rows = block.shape[0]
     assert out.shape[0] == w * rows and out.shape[1:] == block.shape[1:], (out.shape, block.shape, w)
     algo = exchange_algo() if algo is None else algo
-    if w == 1:
+    if w == 1 and not (is_initialized() and block.is_cuda):
         out.copy_(block)
     elif algo == 'mesh':
         out[r * rows:(r + 1) * rows].copy_(block)
@@ -108,7 +110,7 @@ def allgather_blocks(out, block, algo=None):
             to, frm = (r + d) % w, (r - d) % w
             ops.append(torch.distributed.P2POp(torch.distributed.isend, block, to))
             ops.append(torch.distributed.P2POp(torch.distributed.irecv, out[frm * rows:(frm + 1) * rows], frm))
-        for req in torch.distributed.batch_isend_irecv(ops):
+        for req in (torch.distributed.batch_isend_irecv(ops) if ops else ()):    # (a one-rank group has no peers)
             req.wait()
     elif block.is_cuda:
         torch.distributed.all_gather_into_tensor(out, block)
@@ -121,9 +123,11 @@ def allgather_rows(local, n_total, algo=None):
     """local: this rank's [hi-lo, D] block (rows shard_range(n_total)) -> the full [n_total, D]
     on every rank, in dataset order.  One collective (or one group of direct sends: allgather_blocks)."""
     w = world_size()
-    if w == 1:
+    if w == 1 and not (is_initialized() and local.is_cuda):
         assert local.shape[0] == n_total
         return local
+    # (a ONE-rank process group on the GPU takes the collective path too: RCCL runs the same all-gather on itself, so a
+    # one-GPU box exercises communicator, buffers and kernels of the exchange step - tests/test_comm_gpu.py)
     sizes = [shard_range(n_total, r, w) for r in range(w)]
     lo, hi = sizes[rank()]
     assert local.shape[0] == hi - lo, 'shard has %d rows, expected %d' % (local.shape[0], hi - lo)
@@ -159,7 +163,7 @@ def extract_sharded(extract_fn, dataset, trfs, net, width=None, **kw):
     """extract_fn(dataset, trfs, net, **kw) -> [N, D]; under torch.distributed each rank runs it on
     its own shard and the blocks are all-gathered.  `width`: row length when it is not the network's
     descriptor size (the fused multi-scale extraction returns the scales side by side)."""
-    if world_size() == 1:
+    if world_size() == 1 and not (is_initialized() and net.iscuda):
         return extract_fn(dataset, trfs, net, **kw)
     n = len(dataset)
     lo, hi = shard_range(n)

@@ -73,3 +73,61 @@ def test_torch_distributed_rccl_allgather_on_every_gpu():
         mp.spawn(_nccl_worker, args=(world, port, n, out), nprocs=world, join=True)
         res = dict(out)
     assert len(res) == world and all(res.values()), res
+
+
+class _FakeNet(object):
+    iscuda, out_dim, without_fc = True, 64, False
+
+
+def _nccl_ws1_worker(rank, port, n, out):
+    """ONE rank over RCCL: communicator creation with device_id=, the error-agreement all-reduce and the padded
+    all_gather_into_tensor of extract_sharded / allgather_rows on CUDA buffers, the 'mesh' layout's peer loop (no peers at
+    W = 1), barrier, teardown - everything the first multi-GPU run executes except the bytes crossing xGMI."""
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from dirtorch_amd import distributed as dd
+    r, w, local = dd.init_from_env('nccl', force=True)
+    assert (r, w, local) == (0, 1, 0) and dd.is_initialized() and torch.distributed.get_backend() == 'nccl'
+    g = torch.Generator().manual_seed(11)
+    full = torch.randn(n, 64, generator=g)
+    res = {}
+    for algo in ('rccl', 'mesh'):
+        got = dd.allgather_rows(full.cuda(), n, algo=algo)
+        res['rows_' + algo] = bool(torch.equal(got.cpu(), full))
+    calls = []
+
+    def extract(ds, trfs, net):
+        calls.append(len(ds))
+        return full[ds.lo:ds.lo + len(ds)].cuda()
+
+    class DS(object):
+        def __len__(self):
+            return n
+    got = dd.extract_sharded(extract, DS(), None, _FakeNet())
+    res['extract_sharded'] = bool(torch.equal(got.cpu(), full)) and calls == [n]
+
+    def boom(ds, trfs, net):
+        raise FloatingPointError('planted')
+    try:
+        dd.extract_sharded(boom, DS(), None, _FakeNet())
+        res['error_agreement'] = False
+    except FloatingPointError:
+        res['error_agreement'] = True
+    out.update(res)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_torch_distributed_rccl_at_world_size_one():
+    """The multi-rank code on the ONE GPU a gpurun box has (round-5 review, item 4): a fresh process joins a one-rank
+    'nccl' group and runs the exchange step of dirtorch_amd.distributed on CUDA tensors through RCCL itself."""
+    import os
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_nccl_ws1_worker, args=(port, 1003, out), nprocs=1, join=True)
+        res = dict(out)
+    assert res and all(res.values()), res
