@@ -390,8 +390,9 @@ def bench_distractors(args, world, rank, dist):
     # range is established ONCE per database, outside the timed steps, the way a retrieval service would (ranking.is_unit_range)
     unit = not args.sim_general and ranking.is_unit_range(qs, local)
     sim = lambda q, b: ops.similarity(q, b, unit_range=unit)   # noqa: E731
-    full = torch.empty(world * rows, D, device='cuda') if args.exchange == 'descriptors' and world > 1 else None
-    sc_all = torch.empty(world, Q, rows, device='cuda') if args.exchange == 'scores' and world > 1 else None
+    xch = dist is not None      # a process group exists (also a ONE-rank one, under torch.distributed.run): the exchange step runs through RCCL
+    full = torch.empty(world * rows, D, device='cuda') if args.exchange == 'descriptors' and xch else None
+    sc_all = torch.empty(world, Q, rows, device='cuda') if args.exchange == 'scores' and xch else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_x, t_s, t_r = [], [], []
 
@@ -399,18 +400,18 @@ def bench_distractors(args, world, rank, dist):
         if record:
             ev[0].record()
         if args.exchange == 'descriptors':
-            if world > 1:
+            if xch:
                 ddist.allgather_blocks(full, local)                   # the one exchange step (RCCL over xGMI; DIRTORCH_AMD_EXCHANGE=mesh: direct sends)
             if record:
                 ev[1].record()
             # (shards of unequal length - 1 006 322 % 8 = 2 - arrive padded and are scored block by block:
             # dirtorch_amd.distributed.score_gathered, tests/test_ranking_gpu.py::test_sharded_scoring_*)
-            scores = ddist.score_gathered(qs, full, N, world, sim) if world > 1 else sim(qs, local[:N])
+            scores = ddist.score_gathered(qs, full, N, world, sim) if xch else sim(qs, local[:N])
         else:
             mine = sim(qs, local)                                     # [Q, rows] (padding rows score 0)
             if record:
                 ev[1].record()
-            if world > 1:
+            if xch:
                 ddist.allgather_blocks(sc_all.view(world * Q, rows), mine)
                 scores = ddist.merge_score_blocks(sc_all, N, world)
             else:
