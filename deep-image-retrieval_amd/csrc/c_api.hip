@@ -221,6 +221,40 @@ int dir_stem_pool_pair(const void* s2d_hi, const void* s2d_lo, const void* w_hi,
     DIR_CATCH
 }
 
+int dir_stem_pool_u8(const void* img_u8, const float* w_oihw, const float* bn_scale, const float* bn_bias, const float* mean3,
+                     const float* std3, void* s2d_ws, void* y_hi, void* y_lo, int B, int H, int W, int seg_tiles, void* stream) {
+    DIR_TRY
+    if (!img_u8 || !w_oihw || !bn_scale || !bn_bias || !mean3 || !std3 || !s2d_ws || !y_hi || !y_lo)
+        return fail(DIR_ERR_INVALID, "stem_pool_u8: null pointer");
+    if (B <= 0 || H < 7 || W < 7) return fail(DIR_ERR_INVALID, "stem_pool_u8: bad dimension (the image must hold the 7x7 filter)");
+    std::vector<uint16_t> hi, lo;
+    std::vector<float> b2, corr;
+    int rc = fold_stem_u8(w_oihw, bn_scale, bn_bias, mean3, std3, hi, lo, b2, corr);
+    if (rc != DIR_OK) return rc;
+    // (a per-call upload: this is the parity entry point; the engine folds once at finalize and keeps the tables)
+    char* d = nullptr;
+    const size_t nw = hi.size() * 2, nb = b2.size() * 4, nc = corr.size() * 4;
+    DIR_HIP_CHECK(hipMalloc((void**)&d, 2 * nw + nb + nc));
+    hipError_t e = hipMemcpy(d, hi.data(), nw, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + nw, lo.data(), nw, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * nw, b2.data(), nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * nw + nb, corr.data(), nc, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(DIR_ERR_HIP, std::string("stem_pool_u8 upload: ") + hipGetErrorString(e));
+    }
+    rc = prep_input_u8(img_u8, s2d_ws, B, H, W, (hipStream_t)stream);
+    if (rc == DIR_OK)
+        rc = stem_pool_u8_launch(s2d_ws, d, d + nw, (const float*)(d + 2 * nw), (const float*)(d + 2 * nw + nb), y_hi, y_lo, B, H, W,
+                                 (hipStream_t)stream, nullptr, seg_tiles);
+    e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d);
+    if (rc != DIR_OK) return rc;
+    if (e != hipSuccess) return fail(DIR_ERR_HIP, std::string("stem_pool_u8: ") + hipGetErrorString(e));
+    return DIR_OK;
+    DIR_CATCH
+}
+
 int dir_engine_overflow(dir_engine* e, void* stream, int* overflowed) {
     DIR_TRY
     if (!e || !overflowed) return fail(DIR_ERR_INVALID, "overflow: null argument");

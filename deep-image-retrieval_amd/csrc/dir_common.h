@@ -52,6 +52,8 @@ struct Env {
     bool sim_v1 = false, sim_exact = false;      // ..._SIM_V1 (one-role kernel), ..._SIM_EXACT (fp32 MFMA chain at any size)
     bool experiments = false;                    // ..._EXPERIMENTS: opt-in kernels of an experiments build (conv_ring / conv_seam3)
     bool no_inplace = false;                     // ..._NO_INPLACE: layers 3-4's identity blocks ping-pong again instead of writing their output in place
+    bool no_stem_u8 = false;                     // ..._NO_STEM_U8: DIR_FP16P on the uint8 feed takes the generic paired stem (image pair, three MFMAs per term) again
+    int stem_u8_seg = 0;                         // ..._STEM_U8_SEG = T: stem_u8.hip walks segments of T tiles (4 T - 1 pooled rows); 0 = its own choice, 1 = independent tiles
 };
 const Env& env();
 void reload_env();

@@ -86,6 +86,13 @@ struct dir_engine {
     // fp16 overflow word (dir_common.h Ovf): every kernel that packs fp32 sums for a store ORs into it; sticky
     // until dir_engine_overflow() reads and clears it
     int* d_ovf = nullptr;
+    // DIR_FP16P on the raw uint8 feed (stem_u8.hip): conv1 + bn1 with ToTensor / Normalize folded in - filter pair, bias and the
+    // border-class bias corrections (the desc's mean / std are part of them: a new preprocess means a new engine)
+    uint16_t* d_stem_u8_w = nullptr;
+    uint16_t* d_stem_u8_w_lo = nullptr;
+    float* d_stem_u8_bias = nullptr;
+    float* d_stem_u8_corr = nullptr;
+    int fold_stem_u8(dir::ConvLayer& L, const float* w, const float* scale, const float* bias);
     // profiling
     bool profiling = false;
     bool prof_paused = false;

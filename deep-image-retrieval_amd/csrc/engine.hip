@@ -51,6 +51,8 @@ static Env read_env() {
     e.sim_exact = on("DIRTORCH_AMD_SIM_EXACT");
     e.experiments = on("DIRTORCH_AMD_EXPERIMENTS");
     e.no_inplace = on("DIRTORCH_AMD_NO_INPLACE");
+    e.no_stem_u8 = on("DIRTORCH_AMD_NO_STEM_U8");
+    if (const char* s = getenv("DIRTORCH_AMD_STEM_U8_SEG")) e.stem_u8_seg = atoi(s);
     return e;
 }
 static Env& env_slot() {
@@ -249,6 +251,10 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_bias, L.Cout * 4));
         DIR_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), L.Cout * 4, hipMemcpyHostToDevice));
         L.tuned.clear();
+        if (L.stem && dt == DIR_FP16P) {
+            const int rc = fold_stem_u8(L, w->data.data(), scale.data(), bias.data());
+            if (rc != DIR_OK) return rc;
+        }
         if (dt == DIR_F32) {
             DIR_HIP_CHECK(hipMalloc((void**)&L.d_wf, packed.size() * 4));
             DIR_HIP_CHECK(hipMemcpy(L.d_wf, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
@@ -349,7 +355,36 @@ int dir_engine::finalize(int dt) {
     return DIR_OK;
 }
 
+// ---- the stem for the RAW uint8 feed (stem_u8.hip) ------------------------------------------------------------------------
+// ToTensor + Normalize (dirtorch/utils/transforms.py:617-623: x = (u / 255 - mean_c) / std_c) folded into conv1 + bn1
+// (resnet.py:115-117).  The image plane holds u / 256 (exact in fp16), so
+//   w'[o][tap][c] = w . bn_scale[o] . 256 / (255 std_c)                       an fp16 pair, packed like the s2d stem filter
+//   b'[o]         = bn_bias[o] - sum_{all 147 taps} w . bn_scale[o] . mean_c / std_c
+//   corr[rc][cc][o] = + sum_{taps OUTSIDE the image for border class (rc, cc)} w . bn_scale[o] . mean_c / std_c
+// (a padded tap is zero in normalised space, i.e. it must NOT contribute its - mean / std; classes as stem_u8.hip's
+// border_class: 0 all taps r = 0..6 inside, 1: r >= 3, 2: r >= 1, 3 / 4 / 5: r <= 5 / 4 / 3).  Sums in double.
+int dir_engine::fold_stem_u8(ConvLayer& L, const float* w, const float* scale, const float* bias) {
+    (void)L;
+    std::vector<uint16_t> hi, lo;
+    std::vector<float> b2, corr;
+    const int rc = dir::fold_stem_u8(w, scale, bias, desc.mean, desc.std, hi, lo, b2, corr);
+    if (rc != DIR_OK) return rc;
+    DIR_HIP_CHECK(hipMalloc((void**)&d_stem_u8_w, hi.size() * 2));
+    DIR_HIP_CHECK(hipMemcpy(d_stem_u8_w, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+    DIR_HIP_CHECK(hipMalloc((void**)&d_stem_u8_w_lo, lo.size() * 2));
+    DIR_HIP_CHECK(hipMemcpy(d_stem_u8_w_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    DIR_HIP_CHECK(hipMalloc((void**)&d_stem_u8_bias, b2.size() * 4));
+    DIR_HIP_CHECK(hipMemcpy(d_stem_u8_bias, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+    DIR_HIP_CHECK(hipMalloc((void**)&d_stem_u8_corr, corr.size() * 4));
+    DIR_HIP_CHECK(hipMemcpy(d_stem_u8_corr, corr.data(), corr.size() * 4, hipMemcpyHostToDevice));
+    return DIR_OK;
+}
+
 void dir_engine::release() {
+    for (void** p : {(void**)&d_stem_u8_w, (void**)&d_stem_u8_w_lo, (void**)&d_stem_u8_bias, (void**)&d_stem_u8_corr}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
     for (ConvLayer& L : convs) {
         if (L.d_w) (void)hipFree(L.d_w);
         if (L.d_wf) (void)hipFree(L.d_wf);
@@ -651,6 +686,22 @@ int dir_engine::forward_pair_stem(const void* img, int B, int H, int W, int fmt,
     uint16_t* s2d = (uint16_t*)(base + p.s2d);
     uint16_t* s2d_lo = (uint16_t*)(base + p.lo_s2d);
     int rc;
+    if (img && fmt == DIR_IMG_U8_NHWC && d_stem_u8_w && !sw.no_stem_u8) {
+        // the raw uint8 image is exact in ONE fp16 plane: Normalize folded into the filter pair and the bias, two MFMAs per
+        // term, pooled in registers (stem_u8.hip)
+        rc = prof_begin("prep_input", "prep_input_u8", 0, (double)B * H * W * 3 + (double)B * p.H2 * p.W2 * 32, stream);
+        if (rc != DIR_OK) return rc;
+        rc = prep_input_u8(img, s2d, B, H, W, stream);
+        if (rc != DIR_OK) return rc;
+        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        rc = prof_begin("conv1+maxpool", "stem_pool_u8", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
+                        2.0 * (double)B * p.H2 * p.W2 * 16 + 4.0 * ((double)B * p.PH * p.PW * 64 + 64 * 256), stream);
+        if (rc != DIR_OK) return rc;
+        rc = stem_pool_u8_launch(s2d, d_stem_u8_w, d_stem_u8_w_lo, d_stem_u8_bias, d_stem_u8_corr, (uint16_t*)(base + p.bufA),
+                                 (uint16_t*)(base + p.lo_stem), B, H, W, stream, d_ovf, sw.stem_u8_seg);
+        if (rc != DIR_OK) return rc;
+        return prof_end(stream);
+    }
     if (img) {
         rc = prof_begin("prep_input", "prep_input_pair", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
                         (double)B * p.H2 * p.W2 * 64, stream);

@@ -1,5 +1,7 @@
 // pointwise.h — launchers of the HBM-bound kernels (pointwise.hip) and the fp32 NT GEMM (gemm_f32.hip).
 #pragma once
+#include <vector>
+
 #include "dir_common.h"
 
 namespace dir {
@@ -26,6 +28,12 @@ int prep_input_pair(const void* img, int fmt, const float* mean3, const float* s
 int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
                           void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream,
                           int* ovf = nullptr);
+// DIR_FP16P on the raw uint8 feed (stem_u8.hip): one exact plane of u / 256, Normalize folded into the filter pair / bias / border table
+int fold_stem_u8(const float* w, const float* scale, const float* bias, const float* mean3, const float* std3,
+                 std::vector<uint16_t>& hi, std::vector<uint16_t>& lo, std::vector<float>& b2, std::vector<float>& corr);
+int prep_input_u8(const void* img, void* out, int B, int H, int W, hipStream_t stream);
+int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, const float* bias, const float* corr, void* y_hi,
+                        void* y_lo, int B, int H, int W, hipStream_t stream, int* ovf = nullptr, int seg_tiles = 0);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
 int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* pscores, const int* pos_off,

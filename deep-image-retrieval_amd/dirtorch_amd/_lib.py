@@ -73,6 +73,7 @@ SIGNATURES = {
     'dir_prep_input_pair': (c_int, [c_void_p, c_int, POINTER(c_float), POINTER(c_float), c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_void_p]),
     'dir_stem_pool_pair': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    'dir_stem_pool_u8': (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_void_p]),
     'dir_engine_overflow': (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
     'dir_conv_heuristic': (c_int, [c_int] * 12 + [c_char_p, c_int, POINTER(c_int)]),
     'dir_conv_variant_admissible': (c_int, [c_int] * 13 + [POINTER(c_int)]),

@@ -441,3 +441,27 @@ def stem_pool_pair(s2d, w_packed, bias, out_hw):
     call('dir_stem_pool_pair', ptr(s_hi), ptr(s_lo), ptr(w_hi), ptr(w_lo), ptr(bias), ptr(y_hi), ptr(y_lo), B, H2, W2,
          OH, OW, stream_ptr())
     return y_hi, y_lo
+
+
+def stem_pool_u8(img_u8, w_oihw, bn_scale, bn_bias, mean, std, seg_tiles=0):
+    """dir_stem_pool_u8: raw uint8 NHWC image [B,H,W,3] (device) + conv1.weight [64,3,7,7], the folded bn1 scale / bias (host
+    fp32) and the preprocess mean / std -> pooled (hi, lo) [B,PH,PW,64]: ToTensor + Normalize + conv 7x7 s2 + BN + ReLU +
+    MaxPool 3x3 s2 with the normalisation folded into the filter pair (transforms.py:617-623, resnet.py:115-119)."""
+    _need_cuda(img_u8)
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[3] != 3:
+        raise TypeError('image must be uint8 NHWC [B,H,W,3]')
+    B, H, W, _ = img_u8.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    w = w_oihw.detach().to('cpu', torch.float32).contiguous()
+    sc = bn_scale.detach().to('cpu', torch.float32).contiguous()
+    bi = bn_bias.detach().to('cpu', torch.float32).contiguous()
+    assert tuple(w.shape) == (64, 3, 7, 7) and sc.numel() == 64 and bi.numel() == 64
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    ws = torch.empty(B * ((H + 1) // 2) * ((W + 1) // 2) * 32, dtype=torch.uint8, device=img_u8.device)
+    y_hi = torch.empty(B, PH, PW, 64, dtype=torch.float16, device=img_u8.device)
+    y_lo = torch.empty_like(y_hi)
+    call('dir_stem_pool_u8', ptr(img_u8.contiguous()), ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(sc.data_ptr()),
+         ctypes.c_void_p(bi.data_ptr()), m, s, ptr(ws), ptr(y_hi), ptr(y_lo), B, H, W, int(seg_tiles), stream_ptr())
+    return y_hi, y_lo

@@ -165,6 +165,16 @@ int dir_prep_input_pair(const void* img, int img_format, const float* mean3, con
                         void* out_lo, int B, int H, int W, void* stream);
 int dir_stem_pool_pair(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
                        void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, void* stream);
+/* DIR_FP16P on the RAW uint8 feed (stem_u8.hip; what dir_forward runs for DIR_IMG_U8_NHWC input): ToTensor + Normalize
+ * (dirtorch/utils/transforms.py:617-623) + conv1 7x7 s2 + bn1 + ReLU + MaxPool 3x3 s2 (dirtorch/nets/backbones/resnet.py:115-119,
+ * 158-161) from the uint8 NHWC image to the pooled fp16 pair [B,PH,PW,64] x 2.  The integers 0..255 are exact in one fp16 plane, so
+ * the image needs no lo plane: the normalisation is folded into the filter PAIR (w . bn_scale . 256 / (255 std_c)), the bias and a
+ * per-border-class bias table (zero padding happens AFTER Normalize in the reference), two MFMAs per term.  w_oihw: conv1.weight
+ * [64,3,7,7] fp32 (host); bn_scale / bn_bias: bn1 in eval mode folded to y = conv * scale + bias (host, 64 each); s2d_ws: device
+ * scratch of B * ceil(H/2) * ceil(W/2) * 32 bytes; seg_tiles: 0 = the kernel's own segment length, 1 = independent tiles.
+ * Synchronises `stream` (parity entry point: the engine folds once at dir_engine_finalize). */
+int dir_stem_pool_u8(const void* img_u8, const float* w_oihw, const float* bn_scale, const float* bn_bias, const float* mean3,
+                     const float* std3, void* s2d_ws, void* y_hi, void* y_lo, int B, int H, int W, int seg_tiles, void* stream);
 /* fp16 range check.  The reference computes in fp32 and cannot overflow (dirtorch/nets/backbones/resnet.py:67-87);
  * DIR_FP16 storage saturates at 65504.  Every kernel that packs fp32 sums into fp16 for a store ORs into an
  * engine-owned device word when it stores an inf / NaN - the first overflow of a forward is always such a store,

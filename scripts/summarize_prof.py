@@ -171,7 +171,8 @@ def bench_kernel_name(k):
             'prep_input_f32_kernel': 'prep_input_f32', 'maxpool_f32_kernel': 'maxpool_f32',
             'global_pool_f32_kernel': 'global_pool_f32', 'upsample_add_f32_kernel': 'upsample_add_f32',
             'stem_pool_pair_kernel': 'stem_pool_pair', 'stem_pool_pair_persist_kernel': 'stem_pool_pair',
-            'prep_input_pair_kernel': 'prep_input_pair'}.get(k, k)
+            'prep_input_pair_kernel': 'prep_input_pair',
+            'stem_pool_u8_kernel': 'stem_pool_u8', 'prep_input_u8_kernel': 'prep_input_u8'}.get(k, k)
 
 
 def layer_group(name):

@@ -231,7 +231,8 @@ def test_profile_tooling_knows_every_engine_kernel():
     variants = set(ops.conv_variant_names())
     forward = {'stem_pool', 'prep_input', 'global_pool', 'gemm_nt_f32', 'maxpool_3x3s2', 'upsample_add',
                'prep_input_f32', 'maxpool_f32', 'global_pool_f32', 'upsample_add_f32',      # + the strict path's
-               'stem_pool_pair', 'prep_input_pair'}                                        # + the paired head's
+               'stem_pool_pair', 'prep_input_pair',                                        # + the paired head's
+               'stem_pool_u8', 'prep_input_u8'}                                            # + its uint8-feed form (stem_u8.hip)
     other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_sort_kernel', 'rank_hist_kernel', 'rank_finalize_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
              'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'sim_split_lc_kernel', 'split_queries_kernel', 'fill_noise_kernel',
              'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel'}
