@@ -59,6 +59,41 @@ PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.29 TB/s measure
 GFLOP_PER_IMG = {('resnet101', 1024): 325.99, ('resnet50', 224): 8.183}
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)     # dirtorch/nets/backbones/resnet.py:110-111
+
+
+def to_uint8_nhwc(x, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """Normalised fp32 NCHW pictures (tests/synth.py) -> the raw uint8 NHWC images they would have been decoded from
+    (PIL -> np.uint8 HWC, dirtorch/utils/transforms.py:617-623 run backwards, rounded and clamped)."""
+    m, s_ = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+    return ((x * s_ + m) * 255.0).round().clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def normalise_uint8(u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """What the REFERENCE feeds its network for a uint8 image: ToTensor (/ 255) then Normalize, fp32 NCHW."""
+    m, s_ = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+    return ((u8.permute(0, 3, 1, 2).float() / 255.0) - m) / s_
+
+
+def bench_state_dict(arch, size, kind, dist=None, rank=0):
+    """The checkpoint the timed step runs: 'calibrated' = tests/synth.py's He-init weights with BatchNorm statistics calibrated
+    on two synthetic images of the bench size (one fp32 CPU forward; the conditioned network the parity numbers are quoted on),
+    'he' = the plain He-init checkpoint of rounds 1-5.  Under torch.distributed rank 0 calibrates and the others load its file."""
+    import synth
+    if kind == 'he':
+        return synth.synth_state_dict(arch, seed=7)
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dir_bench_calibrated_%s_%d_%d.pt' % (arch, size, os.getuid()))
+    if dist is None or rank == 0:
+        sd = synth.calibrated_state_dict(arch, synth.synth_images(99, 2, size, size), seed=7)
+        if dist is not None:
+            torch.save(sd, path)
+    if dist is not None:
+        dist.barrier()
+        if rank != 0:
+            sd = torch.load(path, weights_only=True)
+    return sd
+
+
 def cpu_allotted():
     """CPUs this process may actually use: the cgroup quota when there is one, else the affinity mask."""
     try:
@@ -170,7 +205,7 @@ def grouped_rate(step, items_per_step, steps=20, group=5, warm=2):
     return round(rates[len(rates) // 2], 1), round(rates[0], 1), round(rates[-1], 1)
 
 
-def precision_leg(arch, size, batch, x_bench, cpu_seconds, headline_dtype='fp16p'):
+def precision_leg(arch, size, batch, x_bench, cpu_seconds, headline_dtype='fp16p', feed='f32', sd_cal=None, sd_rate=None):
     """Outside the timed region, rank 0 at N = 1: what the three storage formats cost and what they lose.
 
       images_per_sec   the same step as the headline in the other storage formats - bf16 (what BASELINE configs[1] names),
@@ -199,7 +234,7 @@ def precision_leg(arch, size, batch, x_bench, cpu_seconds, headline_dtype='fp16p
 
     out = {'images_per_sec': {}, 'images_per_sec_spread': {}, 'one_minus_cos': {}, 'map': {}}
     # ---- throughput of the OTHER formats on the headline workload (>= 20 steps each, rate per group of 5) ----------
-    sd0 = synth.synth_state_dict(arch, seed=7)
+    sd0 = sd_rate if sd_rate is not None else synth.synth_state_dict(arch, seed=7)
     others = [(d, batch, 20) for d in ('bf16', 'fp16', 'fp16p') if d != headline_dtype] + [('f32', max(1, batch // 4), 20)]
     for dtype, b, steps in others:
         net = engine(sd0, dtype)
@@ -211,11 +246,14 @@ def precision_leg(arch, size, batch, x_bench, cpu_seconds, headline_dtype='fp16p
         del net
         torch.cuda.empty_cache()
     # ---- descriptors vs the CPU oracle at the bench size, calibrated checkpoint --------------------------
-    sd = synth.calibrated_state_dict(arch, synth.synth_images(99, 2, size, size), seed=7)
+    sd = sd_cal if sd_cal is not None else synth.calibrated_state_dict(arch, synth.synth_images(99, 2, size, size), seed=7)
     xp = synth.synth_images(4, 2, size, size)
+    if feed == 'u8':      # the engine gets the raw uint8 pictures, the oracle what the reference makes of them (ToTensor + Normalize)
+        xp8 = to_uint8_nhwc(xp)
+        xp = normalise_uint8(xp8)
     cpu, ref = cpu_baseline(arch, size, cpu_seconds, sd=sd, images=xp)
     xin = x_bench.clone()
-    xin[:2] = xp.cuda()
+    xin[:2] = (xp8 if feed == 'u8' else xp).cuda()
     for dtype in ('bf16', 'fp16', 'fp16p', 'f32'):
         net = engine(sd, dtype)
         b = batch if dtype != 'f32' else max(2, batch // 4)
@@ -223,7 +261,8 @@ def precision_leg(arch, size, batch, x_bench, cpu_seconds, headline_dtype='fp16p
         out['one_minus_cos'][dtype] = float('%.3g' % (1 - O.cosine(got, ref)).max())
         del net
         torch.cuda.empty_cache()
-    out['one_minus_cos']['checkpoint'] = 'BatchNorm-calibrated synthetic (tests/synth.py), 2 images inside the batch'
+    out['one_minus_cos']['checkpoint'] = 'BatchNorm-calibrated synthetic (tests/synth.py), 2 images inside the batch, %s feed' % (
+        'uint8 NHWC' if feed == 'u8' else 'fp32 NCHW')
     # ---- mAP through the whole post-extraction path ----------------------------------------------------------
     # (ResNet-18: with random weights the deeper trunks are chaotic - noisy copies of an image decorrelate, the
     # oracle's own mAP sits at chance (0.03 for R101, 0.09 for R50) and a dmAP there measures nothing; on R18 the
@@ -269,7 +308,7 @@ def other_workloads(args, x_bench):
     del x_bench
     torch.cuda.empty_cache()
     for name, fn, over in (('distractors', bench_distractors, {'steps': 20, 'warmup': 2, 'cpu_seconds': 0.0}),
-                           ('multiscale', bench_multiscale, {'steps': 20, 'warmup': 2})):
+                           ('multiscale', bench_multiscale, {'steps': 20, 'warmup': 2})):      # (keeps --cpu-seconds: its parity leg)
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
@@ -284,7 +323,9 @@ def other_workloads(args, x_bench):
             else:
                 out[name] = {'images_per_sec_3scale': r['value'], 'steps': a.steps, 'ms_per_step': r['ms_per_step'],
                              'ms_per_step_spread': r['ms_per_step_spread'], 'batch': a.ms_batch,
-                             'size': a.ms_size, 'step_mfma_frac': r['roofline']['frac'], 'dtype': r['dtype']}
+                             'size': a.ms_size, 'step_mfma_frac': r['roofline']['frac'], 'dtype': r['dtype'],
+                             **{k: r['config'][k] for k in ('one_minus_cos', 'tolerance', 'meets_tolerance', 'parity_sample',
+                                                            'fp16_images_per_sec_3scale') if k in r['config']}}
         except Exception as e:      # noqa: BLE001 - report and go on
             out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         torch.cuda.empty_cache()
@@ -505,29 +546,44 @@ def bench_distractors(args, world, rank, dist):
 
 def bench_multiscale(args, world, rank, dist):
     """BASELINE configs[4]: ResNet-101 GeM, THREE-scale descriptors (x 0.7071 / 1 / 1.4142, dirtorch/test_dir.py:111-122
-    + utils/common.py:41-55) of 1200 x 1200 images, fp16, image-parallel over the ranks (replicated weights, each rank its
+    + utils/common.py:41-55) of 1200 x 1200 images, image-parallel over the ranks (replicated weights, each rank its
     own contiguous image range, no data-path collective), ONE all-gather of the descriptor blocks at the end.  A step =
     one batch of uint8 images resident in HBM -> Pillow-identical resize per scale (resize.hip) -> dir_forward per scale
-    -> GeM pooling over the scales + L2.  value = 3-scale images/s, whole job; scaling 'weak'."""
+    -> GeM pooling over the scales + L2.  value = 3-scale images/s, whole job; scaling 'weak'.
+    Round 6: computed in --dtype (fp16p by default: configs[4] says "fp16 MFMA", and plain fp16 does not meet the 1e-4 cosine
+    on a conditioned network at every size - 1.24e-4 at config A; fp16p runs the same fp16 MFMAs with a paired head); the
+    plain-fp16 rate rides along, and with --cpu-seconds > 0 one image's 3-scale descriptor is checked against the CPU oracle
+    (resize -> ToTensor / Normalize -> forward per scale -> pool -> L2) on the BatchNorm-calibrated checkpoint."""
     import synth
     from dirtorch_amd import nets, ops
     from dirtorch_amd.utils import common, transforms
-    net = nets.create_model(args.arch + '_rmac', pretrained='')
-    net.load_state_dict(synth.synth_state_dict(args.arch, seed=7))
-    net.compute_dtype = 'fp16'
-    net.cuda().eval()
     B, S, K, Wm = args.ms_batch, args.ms_size, args.steps, args.warmup
+    parity = world == 1 and getattr(args, 'cpu_seconds', 0) > 0
+    sd = (synth.calibrated_state_dict(args.arch, synth.synth_images(99, 1, S, S), seed=7) if parity
+          else synth.synth_state_dict(args.arch, seed=7))
+
+    def engine(dtype):
+        n_ = nets.create_model(args.arch + '_rmac', pretrained='')
+        n_.load_state_dict(sd)
+        n_.compute_dtype = dtype
+        return n_.cuda().eval()
+    net = engine(args.dtype)
     g = torch.Generator(device='cuda').manual_seed(99 + rank)
     img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda', generator=g)
+    pic = None
+    if parity:      # one structured picture travels inside the batch: the row the oracle checks
+        pic = to_uint8_nhwc(synth.synth_images(4, 1, S, S))
+        img[0] = pic[0].cuda()
     scales = [transforms.Scale(0.7071), None, transforms.Scale(1.4142)]
     sizes = [(S, S) if sc is None else sc.target_size((S, S)) for sc in scales]
     shard = torch.empty(K * B, net.out_dim, device='cuda')
 
-    def step():
+    def step(n_=None):
+        n_ = n_ or net
         per_scale = []
         for size in sizes:
             x = img if size == (S, S) else ops.resize_bilinear_u8(img, size)
-            per_scale.append(net(x))
+            per_scale.append(n_(x))
         return common.l2_normalize(common.pool(per_scale, 'gem', 3))
 
     for _ in range(max(Wm, 2)):
@@ -558,6 +614,28 @@ def bench_multiscale(args, world, rank, dist):
     spread = step_spread(step) if world == 1 else None
     if rank != 0:
         return None
+    extra = {}
+    if world == 1 and args.dtype != 'fp16':      # the plain-fp16 rate of the same step (what rounds 3-5 reported for configs[4])
+        n16 = engine('fp16')
+        med, lo_, hi_ = grouped_rate(lambda: step(n16), B, steps=10, group=5)
+        extra['fp16_images_per_sec_3scale'] = med
+        del n16
+    if parity:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import dir_oracle as O
+        torch.set_num_threads(cpu_allotted())
+        got = shard[(K - 1) * B].cpu().numpy()[None]
+        per = []
+        t0 = time.perf_counter()
+        for (w_, h_) in sizes:
+            u = pic[0].numpy() if (w_, h_) == (S, S) else O.resize_bilinear_u8(pic[0].numpy(), w_, h_)
+            per.append(O.rmac_forward(sd, args.arch, normalise_uint8(torch.from_numpy(u)[None])).reshape(1, -1))
+        ref = torch.nn.functional.normalize(O.pool(per, 'gem', 3), dim=1).numpy()
+        extra['one_minus_cos'] = float('%.3g' % (1 - O.cosine(got, ref)).max())
+        extra['tolerance'] = 1e-4
+        extra['meets_tolerance'] = bool(extra['one_minus_cos'] < 1e-4)
+        extra['parity_sample'] = ('one %dx%d picture inside the timed batch, 3 scales, BatchNorm-calibrated checkpoint, CPU oracle '
+                                  '%.1f s on %d threads' % (S, S, time.perf_counter() - t0, torch.get_num_threads()))
     # ResNet-101 trunk: 448.76 GFLOP at 1200^2, quadratic in the side
     gflop = sum(448.76 * (s_[0] * s_[1]) / (1200.0 * 1200.0) for s_ in sizes)
     ips = world * K * B / el
@@ -565,10 +643,10 @@ def bench_multiscale(args, world, rank, dist):
         'metric': 'images/sec 3-scale descriptor extraction (%s-GeM, %dx%d, scales 0.7071/1/1.4142)' % (args.arch, S, S),
         'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': K, 'warmup': Wm,
         'ms_per_step': round(el / K * 1e3, 3), 'ms_per_step_spread': spread, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'fp16', 'data': 'synthetic',
-        'config': {'workload': 'configs[4]: %s-GeM multi-scale (3 scales %s) extraction of %dx%d uint8 images, fp16, '
-                               'image-parallel, one all-gather of descriptor blocks' % (args.arch, [s_[0] for s_ in sizes], S, S),
-                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim),
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'configs[4]: %s-GeM multi-scale (3 scales %s) extraction of %dx%d uint8 images, %s, '
+                               'image-parallel, one all-gather of descriptor blocks' % (args.arch, [s_[0] for s_ in sizes], S, S, args.dtype),
+                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim), **extra,
                    'rccl_ranks': dist.get_world_size() if dist is not None else 0},
         'roofline': {'bound': 'mfma', 'kernel': 'whole step (three dir_forward passes + resize + pooling)',
                      'achieved': round(ips / world * gflop / 1e3, 1), 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s',
@@ -647,6 +725,15 @@ def main():
                     help='storage / MFMA format of the headline step.  Default fp16p: fp16 with the paired head, the fast mode that '
                          'meets the north-star 1e-4 cosine on a conditioned network (bf16, which BASELINE configs[1] names, cannot: '
                          'ideal bf16 storage is 7e-4 there - BASELINE.md section 0); the bf16 rate rides along as config.bf16_images_per_sec')
+    ap.add_argument('--input', default='u8', choices=['u8', 'f32'],
+                    help="what the timed step is fed, resident in HBM: 'u8' (default since round 6) = raw uint8 NHWC images, ToTensor + "
+                         "Normalize on the device inside the step - the feed the drop-in CLIs use (utils/pytorch_loader.py) and the "
+                         "reference's real input (transforms.py:617-623); 'f32' = the normalised fp32 NCHW tensor the reference's "
+                         "net(x) takes (rounds 1-5).  The other feed's rate rides along as config.<feed>_feed_images_per_sec")
+    ap.add_argument('--checkpoint', default='calibrated', choices=['calibrated', 'he'],
+                    help="weights of the timed step: 'calibrated' (default since round 6) = the BatchNorm-calibrated synthetic checkpoint "
+                         "the parity numbers are quoted on (one fp32 CPU forward of two images before the clock starts), 'he' = the "
+                         "plain He-init checkpoint of rounds 1-5; the other one's rate rides along as config.he_init_images_per_sec")
     ap.add_argument('--autotune', action='store_true',
                     help='time every admissible tile variant per layer first (default: the built-in tile heuristic, '
                          'which the tuner no longer beats at this shape)')
@@ -708,14 +795,22 @@ def main():
 
     import synth
     from dirtorch_amd import nets
+    B, S, K, Wm = args.batch, args.size, args.steps, args.warmup
+    sd_timed = bench_state_dict(args.arch, S, args.checkpoint, dist, rank)
     net = nets.create_model(args.arch + '_rmac', pretrained='')
-    net.load_state_dict(synth.synth_state_dict(args.arch, seed=7))
+    net.load_state_dict(sd_timed)
     net.compute_dtype = args.dtype
     net.cuda().eval()
 
-    B, S, K, Wm = args.batch, args.size, args.steps, args.warmup
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
-    x = torch.randn(B, 3, S, S, generator=g, device='cuda')       # normalised-image statistics
+    x_f32 = torch.randn(B, 3, S, S, generator=g, device='cuda')   # normalised-image statistics (the feed of rounds 1-5)
+    # the uint8 feed: pictures with structure (tests/synth.py: low-frequency pattern + noise), eight distinct ones tiled over
+    # the batch and rolled per row so that no two batch rows are equal - raw pixels as PIL would hand them over
+    pics = to_uint8_nhwc(synth.synth_images(1234 + rank, min(B, 8), S, S)).cuda()
+    x_u8 = torch.stack([torch.roll(pics[i % pics.shape[0]], shifts=(7 * (i // pics.shape[0]), 13 * (i // pics.shape[0])), dims=(0, 1))
+                        for i in range(B)])
+    del pics
+    x = x_u8 if args.input == 'u8' else x_f32
     if os.environ.get('DIRTORCH_AMD_BENCH_CONST_INPUT'):            # experiment only (profiles/README.md): constant image ->
         x.zero_()                                                   # spatially constant activations, minimal operand toggling
     D = net.out_dim
@@ -850,6 +945,23 @@ def main():
                 print('%-24s %-36s %8.3f ms %8.1f TF/s %8.1f GB/s' % (
                     name, kern, ms, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
         cpu, precision, workloads = None, None, None
+        side = {}
+        if world == 1:
+            # the same step on the OTHER feed and on the OTHER checkpoint (20 steps each, median over groups of 5)
+            other_x = x_f32 if args.input == 'u8' else x_u8
+            med, lo_, hi_ = grouped_rate(lambda: net(other_x), B)
+            side['%s_feed_images_per_sec' % ('fp32' if args.input == 'u8' else 'u8')] = med
+            side['%s_feed_min_max' % ('fp32' if args.input == 'u8' else 'u8')] = [lo_, hi_]
+            net2 = nets.create_model(args.arch + '_rmac', pretrained='')
+            net2.load_state_dict(bench_state_dict(args.arch, S, 'he') if args.checkpoint == 'calibrated' else sd_timed)
+            net2.compute_dtype = args.dtype
+            net2.cuda().eval()
+            if args.checkpoint == 'calibrated':
+                med, lo_, hi_ = grouped_rate(lambda: net2(x), B)
+                side['he_init_images_per_sec'] = med
+                side['he_init_min_max'] = [lo_, hi_]
+            del net2, other_x
+        del x_f32, x_u8
         if world == 1 and args.cpu_seconds > 0:
             del shard
             net._ws = {}
@@ -857,7 +969,8 @@ def main():
             if args.no_precision:
                 cpu, _ = cpu_baseline(args.arch, S, args.cpu_seconds)
             else:
-                precision, cpu = precision_leg(args.arch, S, B, x, args.cpu_seconds, args.dtype)
+                precision, cpu = precision_leg(args.arch, S, B, x, args.cpu_seconds, args.dtype, feed=args.input,
+                                               sd_cal=sd_timed if args.checkpoint == 'calibrated' else None, sd_rate=sd_timed)
             if not args.no_workloads:
                 workloads = other_workloads(args, x)
         value = world * B * K / el
@@ -868,7 +981,12 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'configs[1]: %s_rmac (AP-GeM head) single-scale %dx%d descriptor extraction, '
                                    '1 process per GPU, synthetic weights + images' % (args.arch, S, S),
-                       'batch_per_gpu': B, 'global_batch': world * B, 'input': 'fp32 NCHW resident in HBM',
+                       'batch_per_gpu': B, 'global_batch': world * B,
+                       'input': ('uint8 NHWC images resident in HBM; ToTensor + Normalize on the device inside the step (the drop-in '
+                                 'CLIs\' feed, transforms.py:617-623)' if args.input == 'u8' else 'fp32 NCHW (normalised) resident in HBM'),
+                       'timed_checkpoint': ('BatchNorm-calibrated synthetic (tests/synth.py; the checkpoint one_minus_cos is quoted on)'
+                                            if args.checkpoint == 'calibrated' else 'He-init synthetic (tests/synth.py)'),
+                       **side,
                        'gflop_per_image': GFLOP_PER_IMG.get((args.arch, S)),
                        # ---- parity of THIS line's dtype as flat scalars (measured in this run, outside the timed region):
                        # 1 - cos of the engine's descriptors vs the fp32 CPU oracle on the BatchNorm-calibrated checkpoint,

@@ -11,7 +11,29 @@ for p in (os.path.join(ROOT, 'deep-image-retrieval_amd'), os.path.join(ROOT, 'or
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+def _cpus_allotted():
+    """CPUs this process may actually run on: the cgroup quota when there is one, else the affinity mask.  (The GPU box shows
+    256 logical CPUs and allots 16: torch's default thread count oversubscribes them and the CPU oracle - most of the GPU
+    suite's wall time - runs several times slower than it has to.)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(round(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
+    try:
+        import torch
+        torch.set_num_threads(_cpus_allotted())
+    except Exception:      # noqa: BLE001 - the thread count is an optimisation, never a reason to fail collection
+        pass
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'experiments: exercises a kernel that only an experiments build of the library has '
                                        '(DIR_EXPERIMENTS=1 csrc/build.sh + DIRTORCH_AMD_LIB=.../libdir_engine_exp.so); '
