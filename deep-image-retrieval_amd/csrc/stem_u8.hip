@@ -50,20 +50,19 @@ __device__ __forceinline__ void split2u(float a, float b, uint32_t& hi, uint32_t
     FP16::unpack(hi, ha, hb);
     lo = FP16::pack(a - ha, b - hb);
 }
-// value of the lane to the left / right (whole-wave shift by one lane; lane 0 / lane 63 keep `v`)
+// value of the lane to the left / right (whole-wave shift by one lane; lane 0 / lane 63 read 0 - both belong to even
+// columns, whose 3-max nobody uses).  old = 0 + bound_ctrl: no tied operand, so no register copies around the DPP move.
 __device__ __forceinline__ float lane_left(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_right(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 
 struct StemU8Args {
     const uint16_t* x;          // s2d plane [B, H2, W2, 16], u / 256
     const uint16_t *wh, *wl;    // folded filter pair [64][4][4][16]
-    const float* bias;          // [64] folded bias (all 147 taps inside the image)
+    const float* bias;          // [64] folded bias (all 147 taps inside the image); added - with the ReLU - to the POOLED values
     const float* corr;          // [6][6][64] border-class corrections (class 0 = interior = zeros)
     uint16_t *yh, *yl;          // pooled pair [B, PH, PW, 64]
     int B, H, W, H2, W2, OH, OW, PH, PW;
@@ -231,8 +230,16 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
                     m0 = *(const f32x4_t*)(X + 7 * XROW + o0);
                     m1 = *(const f32x4_t*)(X + 7 * XROW + o1);
                 }
+                // bias and ReLU commute with the max (both monotone): applied here, to the 8 pooled values of this thread, instead
+                // of to the 32 conv outputs of every lane
+                const f32x4_t bb0 = *(const f32x4_t*)(lbias + c8 * 8), bb1 = *(const f32x4_t*)(lbias + c8 * 8 + 4);
                 u32x4_t oh, ol;
-                const float mv[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+                float mv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mv[e] = fmaxf(m0[e] + bb0[e], 0.f);
+                    mv[4 + e] = fmaxf(m1[e] + bb1[e], 0.f);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     uint32_t hh, ll;
@@ -252,64 +259,77 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
         const char* pbuf = smem + pb * PATCH;
         const int ox = 2 * cur.pw0 - 1 + lrow;
         const int oy = cur.c + 2 * rp;
+        // a tile is an EDGE tile when one of its conv outputs has a 7x7 window that leaves the image (the border-class
+        // correction applies) or lies outside the conv map itself (masked out of the max): 13 % of the tiles at 1024^2
+        const bool edge = cur.c <= 1 || 2 * (cur.c + TH - 1) + 4 > a.H || cur.pw0 == 0 || 2 * (2 * cur.pw0 + TW - 2) + 4 > a.W;
         f32x16_t acc[2];
-        {
-            // accumulators start at the folded bias, + the border-class correction where a 7x7 window leaves the image
-            const bool edge = cur.c <= 1 || 2 * (cur.c + TH - 1) + 4 > a.H || cur.pw0 == 0 || 2 * (2 * cur.pw0 + TW - 2) + 4 > a.W;
+        if (edge) {   // accumulators start at the border-class correction (the folded bias itself is added at the emit)
             const int cc = border_class(min(max(ox, 0), a.OW - 1), a.W);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int rc = border_class(min(max(oy + j, 0), a.OH - 1), a.H);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f32x4_t b4 = *(const f32x4_t*)(lbias + ci * 32 + 8 * g + 4 * lhi);
-                    if (edge) {
-                        const f32x4_t c4 = *(const f32x4_t*)(lcorr + (rc * 6 + cc) * 64 + ci * 32 + 8 * g + 4 * lhi);
+                    const f32x4_t c4 = *(const f32x4_t*)(lcorr + (rc * 6 + cc) * 64 + ci * 32 + 8 * g + 4 * lhi);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) b4[e] += c4[e];
-                    }
+                    for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = c4[e];
+                }
+            }
+        } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = b4[e];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        }
+        // 20 fragments = patch rows 0..4 of this wave's row pair x 4 s2d columns: patch row q feeds conv row j = 0 through filter
+        // row R = q and conv row j = 1 through R = q - 1, so the two rows share 12 of their 16 + 16 fragments.  Fragment of step
+        // s + 1 requested before the MFMAs of step s; the pinned read : MFMA interleave keeps hipcc from hoisting every read
+        // (80 VGPRs) above the chain.
+        const char* xrow = pbuf + lhi * PLANE + ((rp * 2) * QW + lrow) * 16;
+        frag_t xf[2];
+        xf[0] = *(const frag_t*)xrow;
+#pragma unroll
+        for (int s = 0; s < 20; ++s) {
+            const int q = s >> 2, ks = s & 3;
+            if (s + 1 < 20) xf[(s + 1) & 1] = *(const frag_t*)(xrow + (((s + 1) >> 2) * QW + ((s + 1) & 3)) * 16);
+            if (!(DIR_STEMU8_ABL & 1)) {
+                if (q < 4) {
+                    acc[0] = DT::mfma32(wfh[q][ks], xf[s & 1], acc[0]);
+                    acc[0] = DT::mfma32(wfl[q][ks], xf[s & 1], acc[0]);
+                }
+                if (q > 0) {
+                    acc[1] = DT::mfma32(wfh[q - 1][ks], xf[s & 1], acc[1]);
+                    acc[1] = DT::mfma32(wfl[q - 1][ks], xf[s & 1], acc[1]);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          // 1 DS read
+            if (q > 0 && q < 4)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                      // 4 MFMAs (both conv rows)
+            else
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                      // 2 MFMAs (patch rows 0 and 4: one conv row)
+        }
+
+        // ---- conv outputs outside the conv map -> -inf (edge tiles only; every pool window holds a real output), 3-max
+        // along the row in registers: valid in the ODD lanes, window (l - 1, l, l + 1) ---------------------------------
+        if (edge) {
+            const bool col_in = (unsigned)ox < (unsigned)a.OW;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool in = col_in && (unsigned)(oy + j) < (unsigned)a.OH;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float t = acc[j][e];
+                    acc[j][e] = in ? t : -__builtin_inff();
                 }
             }
         }
-        // 16 K-steps (filter row R, s2d column ks), fragments of step s + 1 requested before the four MFMAs of step s; the
-        // pinned 2 reads : 4 MFMAs interleave keeps hipcc from hoisting all 32 fragment reads (128 VGPRs) above the chain
-        const char* xrow = pbuf + lhi * PLANE + ((rp * 2) * QW + lrow) * 16;
-        frag_t xf[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) xf[0][j] = *(const frag_t*)(xrow + (j * QW) * 16);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int R = s >> 2, ks = s & 3;
-            if (s + 1 < 16) {
-                const int R1 = (s + 1) >> 2, k1 = (s + 1) & 3;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)   // patch pixel (row oy + j + R - 2, column ox + ks - 2)
-                    xf[(s + 1) & 1][j] = *(const frag_t*)(xrow + ((j + R1) * QW + k1) * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (DIR_STEMU8_ABL & 1) continue;
-                acc[j] = DT::mfma32(wfh[R][ks], xf[s & 1][j], acc[j]);
-                acc[j] = DT::mfma32(wfl[R][ks], xf[s & 1][j], acc[j]);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs
-        }
-
-        // ---- ReLU, conv outputs outside the image -> 0 (exact for the max of post-ReLU values), 3-max along the row ------
-        const bool col_in = (unsigned)ox < (unsigned)a.OW;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int inmask = (col_in && (unsigned)(oy + j) < (unsigned)a.OH) ? -1 : 0;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float t = acc[j][e];   // (a copy: hipcc 7.2 folds __builtin_bit_cast of a vector-element lvalue to element 0)
-                const float v = __builtin_bit_cast(float, max(__builtin_bit_cast(int, t), 0) & inmask);
-                acc[j][e] = fmaxf(fmaxf(lane_left(v), v), lane_right(v));   // valid in the ODD lanes: window (l - 1, l, l + 1)
+                const float v = acc[j][e];
+                acc[j][e] = fmaxf(fmaxf(lane_left(v), v), lane_right(v));
             }
-        }
         // acc[0] = H (row 2 rp, pooled along the row), m = max(H, row 2 rp + 1) = M
         char* X = smem + X_OFF + xb * XBUF;
         const int px = lrow >> 1;

@@ -27,31 +27,47 @@ def is_unit_range(*tensors):
     return True
 
 
-_RANGE_CACHE = {}     # (data_ptr, shape, dtype, _version) of a database tensor -> is_unit_range verdict (a few entries)
+_RANGE_ATTR = '_dirtorch_unit_range'     # (tensor._version, data_ptr, verdict), kept ON the caller's tensor object
 
 
 def database_is_unit_range(b):
-    """is_unit_range(b), remembered per database TENSOR: the full pass over an 8 GB database (1.5 ms + a host sync) is paid
-    once, not on every query batch - the key carries the tensor's version counter, so an in-place update re-checks."""
-    key = (b.data_ptr(), tuple(b.shape), b.dtype, b._version)
-    hit = _RANGE_CACHE.get(key)
-    if hit is None:
-        if len(_RANGE_CACHE) >= 8:
-            _RANGE_CACHE.clear()
-        hit = _RANGE_CACHE[key] = is_unit_range(b)
-    return hit
+    """is_unit_range(b), remembered ON the database tensor the caller holds: the full pass over an 8 GB database (1.5 ms + a
+    host sync) is paid once per tensor OBJECT, not on every query batch.  The verdict is an attribute of that object, so it
+    dies with it - a new tensor that the caching allocator places at the same address starts without one (round-5 advice:
+    a (data_ptr, shape, version) key could be served to a different upload) - and it carries the version counter and the
+    address it was taken at, so an in-place torch update or a .set_() re-checks.  What torch cannot see - a refill through
+    raw pointers, e.g. by this library's own kernels - must drop it: forget_unit_range(b), or pass unit_range= explicitly."""
+    tag = getattr(b, _RANGE_ATTR, None)
+    if tag is not None and tag[0] == b._version and tag[1] == b.data_ptr():
+        return tag[2]
+    verdict = is_unit_range(b)
+    try:
+        setattr(b, _RANGE_ATTR, (b._version, b.data_ptr(), verdict))
+    except AttributeError:      # (an object that takes no attributes: no caching)
+        pass
+    return verdict
+
+
+def forget_unit_range(b):
+    """Drop the remembered range verdict of a database tensor whose contents were rewritten behind torch's back."""
+    if hasattr(b, _RANGE_ATTR):
+        delattr(b, _RANGE_ATTR)
 
 
 def similarity_device(qdescs, bdescs, unit_range=None):
     """Scores Q.DB^T as a CUDA tensor [Q, N] (common.matmul without the download).  unit_range: True = the caller knows
     both sets are bounded by 60 in magnitude (L2-normalised descriptors: dirtorch/test_dir.py:150) and wants the fp16-pair
     kernel on large databases (ops.similarity); None (default) = look, when the database is large enough for it to matter -
-    the DATABASE's verdict is cached per tensor (database_is_unit_range), only the small query block is checked per call;
+    the DATABASE's verdict is remembered on the caller's own CUDA tensor (database_is_unit_range), only the small query block is checked per call;
     False = never.  Evaluation loops that know their descriptors are L2-normalised pass True."""
     from .utils.common import _dev
     q, b = _dev(qdescs), _dev(bdescs)
     if unit_range is None:
-        unit_range = b.shape[0] >= UNIT_RANGE_MIN_ROWS and database_is_unit_range(b) and is_unit_range(q)
+        # the verdict is only REMEMBERED for a database the caller owns as a float32 CUDA tensor (_dev hands that very object
+        # back); an ndarray / a CPU or non-fp32 tensor is uploaded into a temporary, which is checked in full and forgotten
+        owned = b is bdescs
+        unit_range = (b.shape[0] >= UNIT_RANGE_MIN_ROWS and (database_is_unit_range(b) if owned else is_unit_range(b))
+                      and is_unit_range(q))
     return ops.similarity(q, b, unit_range=bool(unit_range))
 
 

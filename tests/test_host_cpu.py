@@ -435,3 +435,22 @@ def test_pair_similarity_arithmetic_restated_in_numpy():
     assert abs(pair[0, 5] - 1.0) < 1e-7
     dropped = np.abs(ql @ dl.T) / 2.0 ** 20
     assert dropped.max() < 2.0 ** -22 * (np.abs(q).astype(np.float64) @ np.abs(d).astype(np.float64).T).max()
+
+
+def test_unit_range_verdict_lives_on_the_tensor_object(monkeypatch):
+    """ranking.database_is_unit_range remembers its verdict ON the caller's tensor object (round-5 advice: a cache keyed by
+    (data_ptr, shape, dtype, version) can be served to a different upload that the allocator placed at the same address):
+    one full check per object, a re-check after an in-place torch update, none inherited by another object."""
+    from dirtorch_amd import ranking
+    calls = []
+    monkeypatch.setattr(ranking, 'is_unit_range', lambda *t: (calls.append(1), True)[1])
+    a = torch.zeros(4, 4)
+    assert ranking.database_is_unit_range(a) and ranking.database_is_unit_range(a)
+    assert len(calls) == 1
+    a.add_(1)                                   # torch bumps the version counter: looked at again
+    assert ranking.database_is_unit_range(a) and len(calls) == 2
+    b = torch.zeros(4, 4)                       # another object - wherever it lives - starts without a verdict
+    assert ranking.database_is_unit_range(b) and len(calls) == 3
+    ranking.forget_unit_range(b)                # contents rewritten through raw pointers: the caller says so
+    assert ranking.database_is_unit_range(b) and len(calls) == 4
+    assert not hasattr(ranking, '_RANGE_CACHE')
