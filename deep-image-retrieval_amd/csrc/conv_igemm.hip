@@ -577,7 +577,7 @@ int conv_pick_variant(const ConvArgs& a) {
         const bool no_ps = env().no_patchs;  // A/B and bisecting
         if (a.R * a.S > 1 && !no_ps) c[n++] = {"256x256_patch3x3s", 1};
         // (conv_ring.hip's 128x256_ring1x1 - split loader / consumer waves - ties the persistent kernel on these layers
-        // inside the network, gpurun_out/r3f-r3h: it stays a tuner candidate; DIRTORCH_AMD_RING=1 puts it first, for A/B)
+        // inside the network, gpurun_out/r3f-r3h: it stays a tuner candidate; an experiments build + DIRTORCH_AMD_EXPERIMENTS=1 puts it first, for A/B)
 #ifdef DIR_EXPERIMENTS
         if (a.R * a.S == 1 && !a.res && env().experiments) c[n++] = {"128x256_ring1x1", 1};
 #endif
@@ -634,7 +634,7 @@ int conv_pick_dual_variant(const ConvArgs& a, bool any_size) {
 // which workgroup finished first.  8 channels per lane.
 template <class DT>
 __global__ void conv_splitk_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
-                                            const uint16_t* __restrict__ res, uint16_t* __restrict__ y,
+                                            const uint16_t* res, uint16_t* y,   // (no __restrict__: in-place identity blocks pass res == y)
                                             long total8, int Cout, long MC, int ksplit, int relu, int* ovf_flag) {
     const long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i8 >= total8) return;

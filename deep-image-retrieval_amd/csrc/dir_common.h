@@ -38,7 +38,9 @@ int fail(int code, const std::string& msg);
 // ---- A/B switches --------------------------------------------------------------------------------------
 // Every DIRTORCH_AMD_* switch the library honours.  The environment is read ONCE (first use) and again only when the
 // host calls dir_reload_env() - what a test or an A/B script does after flipping a variable inside one process; an
-// engine copies the switches that steer its forward at dir_engine_create.  No launch path calls getenv.
+// engine copies the switches that steer its forward at dir_engine_create (`dir_engine::sw`), the kernel pickers and the
+// per-op entry points read the current process-wide snapshot (include/dir_engine.h lists which is which).  No launch
+// path calls getenv.
 struct Env {
     bool c3c1_off = false, c3c1_force = false;   // DIRTORCH_AMD_C3C1 = 0 | force: the fused conv3 -> conv1 seam kernels
     bool no_ds_seam = false, no_dual = false;    // ..._NO_DS_SEAM, ..._NO_DUAL: the downsample as its own launch again
@@ -53,6 +55,7 @@ struct Env {
     bool experiments = false;                    // ..._EXPERIMENTS: opt-in kernels of an experiments build (conv_ring / conv_seam3)
     bool no_inplace = false;                     // ..._NO_INPLACE: layers 3-4's identity blocks ping-pong again instead of writing their output in place
     bool no_stem_u8 = false;                     // ..._NO_STEM_U8: DIR_FP16P on the uint8 feed takes the generic paired stem (image pair, three MFMAs per term) again
+    bool stem_u8_wg8 = false;                    // ..._STEM_U8_WG8: stem_u8.hip as ONE 8-wave workgroup per CU (8 x 32 conv tiles) instead of two 4-wave ones
     int stem_u8_seg = 0;                         // ..._STEM_U8_SEG = T: stem_u8.hip walks segments of T tiles (4 T - 1 pooled rows); 0 = its own choice, 1 = independent tiles
 };
 const Env& env();

@@ -52,15 +52,35 @@ static Env read_env() {
     e.experiments = on("DIRTORCH_AMD_EXPERIMENTS");
     e.no_inplace = on("DIRTORCH_AMD_NO_INPLACE");
     e.no_stem_u8 = on("DIRTORCH_AMD_NO_STEM_U8");
+    e.stem_u8_wg8 = on("DIRTORCH_AMD_STEM_U8_WG8");
     if (const char* s = getenv("DIRTORCH_AMD_STEM_U8_SEG")) e.stem_u8_seg = atoi(s);
     return e;
 }
-static Env& env_slot() {
-    static Env e = read_env();   // (thread-safe first use)
-    return e;
+// Two snapshots and an atomic index: dir_reload_env fills the idle one and publishes it with one store, so a launch that reads
+// env() concurrently sees the old set or the new one, never a torn struct (round-5 advice).  (A reader that still holds a reference
+// while a SECOND reload recycles its slot is the remaining window: reloads are a test / A-B tool, two per launch do not happen.)
+static Env g_env[2];
+static std::atomic<int> g_env_cur{-1};
+static std::atomic_flag g_env_lock = ATOMIC_FLAG_INIT;
+static void publish_env() {
+    while (g_env_lock.test_and_set(std::memory_order_acquire)) {
+    }
+    const int cur = g_env_cur.load(std::memory_order_relaxed);
+    const int nxt = cur < 0 ? 0 : 1 - cur;
+    g_env[nxt] = read_env();
+    g_env_cur.store(nxt, std::memory_order_release);
+    g_env_lock.clear(std::memory_order_release);
 }
-const Env& env() { return env_slot(); }
-void reload_env() { env_slot() = read_env(); }   // host-driven (dir_reload_env): not concurrent with launches by contract
+const Env& env() {
+    int cur = g_env_cur.load(std::memory_order_acquire);
+    if (cur < 0) {
+        static const bool once = (publish_env(), true);   // (thread-safe first use)
+        (void)once;
+        cur = g_env_cur.load(std::memory_order_acquire);
+    }
+    return g_env[cur];
+}
+void reload_env() { publish_env(); }   // host-driven (dir_reload_env)
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 

@@ -87,17 +87,23 @@ __device__ __forceinline__ int border_class(int o, int n) {
     return o == 0 ? 1 : (o == 1 ? 2 : (t <= 0 ? 0 : 2 + t));
 }
 
-__global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
+// NRP = conv row PAIRS per workgroup (= pooled rows per tile): 4 -> 8 waves, 8 x 32 conv tiles, one workgroup per CU;
+// 2 -> 4 waves, 4 x 32 conv tiles, TWO workgroups per CU - their barriers are independent, so one's matrix phase runs
+// under the other's pooling / emit phase on the same SIMDs (the phases of one workgroup's waves move in lock-step).
+template <int NRP>
+__global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kernel(const StemU8Args a) {
     typedef FP16 DT;
     typedef DT::frag_t frag_t;
     constexpr int PTW = 15;
-    constexpr int TH = 8, TW = 32;
-    constexpr int QW = TW + 3;                  // patch width 35, height TH + 3 = 11
-    constexpr int QP = (TH + 3) * QW;           // 385 patch pixels
-    constexpr int PLANE = 512 * 16;             // one channel-half plane (8 channels x 512 pixel slots)
-    constexpr int PATCH = 2 * PLANE;            // 16 KiB
+    constexpr int NT = 128 * NRP;               // threads
+    constexpr int TH = 2 * NRP, TW = 32;
+    constexpr int QW = TW + 3;                  // patch width 35, height TH + 3
+    constexpr int QP = (TH + 3) * QW;           // 385 / 245 patch pixels
+    constexpr int PLANE = NT * 16;              // one channel-half plane (8 channels x NT pixel slots)
+    constexpr int PATCH = 2 * PLANE;            // 16 / 8 KiB
     constexpr int XROW = 16 * 256;              // one exchanged row: 16 pooled columns x 64 channels fp32
-    constexpr int XBUF = 8 * XROW;              // slots 0-3: M[k] = max of conv rows 2k, 2k+1; 4-6: H[k], k = 1..3 (conv row 2k); 7: KP
+    constexpr int XBUF = 2 * NRP * XROW;        // slots 0..NRP-1: M[k] = max of conv rows 2k, 2k+1; NRP..2NRP-2: H[k], k = 1..NRP-1 (conv row 2k); 2NRP-1: KP
+    static_assert(QP <= NT, "one DMA instruction per plane covers the patch");
     constexpr int X_OFF = 3 * PATCH;
     constexpr int BIAS_OFF = X_OFF + 2 * XBUF;
     constexpr int CORR_OFF = BIAS_OFF + 256;
@@ -125,7 +131,7 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
     float* lbias = (float*)(smem + BIAS_OFF);
     float* lcorr = (float*)(smem + CORR_OFF);
     if (tid < 64) lbias[tid] = a.bias[tid];
-    for (int i = tid; i < 36 * 64; i += 512) lcorr[i] = a.corr[i];
+    for (int i = tid; i < 36 * 64; i += NT) lcorr[i] = a.corr[i];
 
     // ---- tile sequence of this workgroup: items blockIdx.x, + gridDim.x, ...; item = (segment, image, column strip) -------
     auto decode = [&](TileU8& d) {
@@ -138,16 +144,16 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
         const int seg = r / a.B;
         const int ps = seg * a.seg_rows;
         d.pe = min(a.PH, ps + a.seg_rows);
-        d.nt = (d.pe - ps) / 4 + 1;              // conv rows 2 ps - 1 ... 2 pe - 1 in tiles of 8
+        d.nt = (2 * (d.pe - ps) + TH) / TH;      // conv rows 2 ps - 1 ... 2 pe - 1 (2 n + 1 of them) in tiles of TH
         d.pw0 = tx * PTW;
-        d.pbase = ps + 4 * d.t;
-        d.c = 2 * ps - 1 + 8 * d.t;
+        d.pbase = ps + NRP * d.t;
+        d.c = 2 * ps - 1 + TH * d.t;
     };
     auto advance = [&](TileU8& d) {
         if (!d.valid) return;
         if (++d.t < d.nt) {
-            d.pbase += 4;
-            d.c += 8;
+            d.pbase += NRP;
+            d.c += TH;
         } else {
             d.item += gridDim.x;
             d.t = 0;
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
             const bool ok = p < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
             const uint32_t v = ok ? (uint32_t)((((d.b * a.H2 + iy) * a.W2 + ix) * 16 + i * 8) * 2) : kOOBu;
             if (DIR_STEMU8_ABL & 4) continue;
-            dma16u(rsrc_x, dst + (i * 512 + wave * 64) * 16, v);
+            dma16u(rsrc_x, dst + (i * NT + wave * 64) * 16, v);
         }
     };
 
@@ -211,24 +217,24 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
         // ---- emit tile n - 1: rows k = 0..2 -> max(M[k], H[k + 1]); row 3 -> KP (the row tile n - 2 began), if any -------
         if (prev.valid && !(DIR_STEMU8_ABL & 2)) {
             const char* X = smem + X_OFF + (xb ^ 1) * XBUF;
-            const int r4 = tid >> 7, px = (tid >> 3) & 15, c8 = tid & 7;
-            const int ph = r4 < 3 ? prev.pbase + r4 : prev.pbase - 1;
+            const int r4 = tid >> 7, px = (tid >> 3) & 15, c8 = tid & 7;      // r4 < NRP - 1: row k = r4; r4 = NRP - 1: the carried row
+            const int ph = r4 < NRP - 1 ? prev.pbase + r4 : prev.pbase - 1;
             const int pw = prev.pw0 + px;
-            const bool live = px < PTW && pw < a.PW && ph < prev.pe && (r4 < 3 || prev.t > 0);
+            const bool live = px < PTW && pw < a.PW && ph < prev.pe && (r4 < NRP - 1 || prev.t > 0);
             if (live) {
                 const int o0 = px * 256 + (((2 * c8) ^ (px & 7)) << 4), o1 = px * 256 + (((2 * c8 + 1) ^ (px & 7)) << 4);
                 f32x4_t m0, m1;
-                if (r4 < 3) {
+                if (r4 < NRP - 1) {
                     const f32x4_t a0 = *(const f32x4_t*)(X + r4 * XROW + o0), a1 = *(const f32x4_t*)(X + r4 * XROW + o1);
-                    const f32x4_t b0 = *(const f32x4_t*)(X + (4 + r4) * XROW + o0), b1 = *(const f32x4_t*)(X + (4 + r4) * XROW + o1);
+                    const f32x4_t b0 = *(const f32x4_t*)(X + (NRP + r4) * XROW + o0), b1 = *(const f32x4_t*)(X + (NRP + r4) * XROW + o1);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         m0[e] = fmaxf(a0[e], b0[e]);
                         m1[e] = fmaxf(a1[e], b1[e]);
                     }
                 } else {
-                    m0 = *(const f32x4_t*)(X + 7 * XROW + o0);
-                    m1 = *(const f32x4_t*)(X + 7 * XROW + o1);
+                    m0 = *(const f32x4_t*)(X + (2 * NRP - 1) * XROW + o0);
+                    m1 = *(const f32x4_t*)(X + (2 * NRP - 1) * XROW + o1);
                 }
                 // bias and ReLU commute with the max (both monotone): applied here, to the 8 pooled values of this thread, instead
                 // of to the 32 conv outputs of every lane
@@ -340,11 +346,11 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int off = px * 256 + (((8 * ci + 2 * g + lhi) ^ (px & 7)) << 4);
-                    const f32x4_t m3 = *(const f32x4_t*)(Xp + 3 * XROW + off);
+                    const f32x4_t m3 = *(const f32x4_t*)(Xp + (NRP - 1) * XROW + off);
                     f32x4_t v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(m3[e], acc[0][4 * g + e]);
-                    *(f32x4_t*)(X + 7 * XROW + off) = v;
+                    *(f32x4_t*)(X + (2 * NRP - 1) * XROW + off) = v;
                 }
             }
         }
@@ -359,7 +365,7 @@ __global__ void __launch_bounds__(512) stem_pool_u8_kernel(const StemU8Args a) {
                     m[e] = fmaxf(acc[0][4 * g + e], acc[1][4 * g + e]);
                 }
                 *(f32x4_t*)(X + rp * XROW + off) = m;
-                if (rp > 0) *(f32x4_t*)(X + (3 + rp) * XROW + off) = h;
+                if (rp > 0) *(f32x4_t*)(X + (NRP - 1 + rp) * XROW + off) = h;
             }
         }
 
@@ -487,19 +493,30 @@ int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, con
         return fail(DIR_ERR_INVALID, "stem_pool_u8: input exceeds 2^31 bytes; lower the batch");
     a.x_bytes = (uint32_t)((size_t)B * a.H2 * a.W2 * 32);
     a.tiles_x = (a.PW + 14) / 15;
-    // segment length: 4 T - 1 pooled rows = exactly T tiles of 8 conv rows.  T = 8 unless that leaves CUs without an item.
+    // NRP = 2 (two 4-wave workgroups per CU) unless DIRTORCH_AMD_STEM_U8_WG8 asks for the one-workgroup form.
+    // Segment length: seg_rows = 2 T' - 1 pooled rows are exactly T' tiles of TH conv rows (no wasted row); 31 unless that leaves
+    // workgroup slots without an item.  seg_tiles (DIRTORCH_AMD_STEM_U8_SEG) counts tiles of EIGHT conv rows: 1 = 3 pooled rows.
+    const bool wg8 = env().stem_u8_wg8;
     const int cus = cu_count();
+    const int slots = wg8 ? cus : 2 * cus;
     int T = seg_tiles > 0 ? seg_tiles : 8;
-    while (seg_tiles <= 0 && T > 1 && (long)B * a.tiles_x * ((a.PH + 4 * T - 2) / (4 * T - 1)) < 2L * cus) T >>= 1;
+    while (seg_tiles <= 0 && T > 1 && (long)B * a.tiles_x * ((a.PH + 4 * T - 2) / (4 * T - 1)) < 2L * slots) T >>= 1;
     a.seg_rows = 4 * T - 1;
     a.nseg = (a.PH + a.seg_rows - 1) / a.seg_rows;
     a.nitems = B * a.tiles_x * a.nseg;
     a.ovf = ovf;
-    constexpr int LDS = 3 * 16384 + 2 * 8 * 4096 + 256 + 36 * 64 * 4;
-    static std::atomic<uint64_t> attr{0};
-    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_u8_kernel, LDS, attr));
-    const int grid = a.nitems < cus ? a.nitems : cus;
-    hipLaunchKernelGGL(stem_pool_u8_kernel, dim3((unsigned)grid), dim3(512), LDS, stream, a);
+    const int grid = a.nitems < slots ? a.nitems : slots;
+    if (wg8) {
+        constexpr int LDS = 3 * 16384 + 2 * 8 * 4096 + 256 + 36 * 64 * 4;
+        static std::atomic<uint64_t> attr{0};
+        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_u8_kernel<4>, LDS, attr));
+        hipLaunchKernelGGL(stem_pool_u8_kernel<4>, dim3((unsigned)grid), dim3(512), LDS, stream, a);
+    } else {
+        constexpr int LDS = 3 * 8192 + 2 * 4 * 4096 + 256 + 36 * 64 * 4;
+        static std::atomic<uint64_t> attr{0};
+        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_u8_kernel<2>, LDS, attr));
+        hipLaunchKernelGGL(stem_pool_u8_kernel<2>, dim3((unsigned)grid), dim3(256), LDS, stream, a);
+    }
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;
 }

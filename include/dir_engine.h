@@ -106,8 +106,15 @@ const char* dir_last_error(void);
 const char* dir_version(void);
 /* The DIRTORCH_AMD_* A/B switches (kernel-selection toggles for bisecting; no reference counterpart - the reference reads no
  * environment on this path) are read from the environment ONCE, at the library's first use, and copied into an engine at
- * dir_engine_create.  A host that changes one of them afterwards (tests, A/B scripts) calls this to re-read them; engines
- * created later see the new values.  Not to be called concurrently with launches. */
+ * dir_engine_create.  A host that changes one of them afterwards (tests, A/B scripts) calls this to re-read them.  Two lifetimes:
+ *   per ENGINE (copied at dir_engine_create; an existing engine keeps what it was created with):  _C3C1, _NO_DS_SEAM, _NO_DUAL,
+ *       _REV_CONV1 / _REV_CONV3, _UNFUSED_STEM, _PAIR_ACTS, _PAIR_STAGES (the last two take effect at dir_engine_finalize),
+ *       _NO_INPLACE, _NO_STEM_U8, _STEM_U8_SEG, _EXPERIMENTS (which kernels a forward may consider)
+ *   per PROCESS (read from the current snapshot at every launch, by engines and by the per-op entry points alike):  the kernel
+ *       pickers' _NO_PATCHLC / _NO_WREG / _NO_PATCHW / _NO_PATCHW_LC / _NO_X3 / _NO_PATCHS / _NO_PAIR_PATCH / _NO_XCDMAP,
+ *       _STEM_V1, _SIM_V1, _SIM_EXACT
+ * The re-read builds a new snapshot and publishes it with one atomic store (a launch sees the old set or the new one, never a
+ * mixture); still, do not call it while another thread is launching if that thread's A/B comparison matters. */
 int dir_reload_env(void);
 
 /* ---- model life cycle: replaces nets.create_model + net.load_state_dict + net.cuda() ------- */

@@ -10,6 +10,7 @@ done
 for seg in 1 2 4 16; do
   DIRTORCH_AMD_STEM_U8_SEG=$seg timeout 200 python scripts/exp_stem_u8_time.py 2>&1 | grep -v amdgpu.ids >> $O/stem_u8_phases.txt
 done
+DIRTORCH_AMD_STEM_U8_WG8=1 timeout 200 python scripts/exp_stem_u8_time.py 2>&1 | grep -v amdgpu.ids | sed "s/^/one 8-wave workgroup per CU  /" >> $O/stem_u8_phases.txt
 EXP_PICS=1 timeout 200 python scripts/exp_stem_u8_time.py 2>&1 | grep -v amdgpu.ids | sed "s/^/synthetic pictures  /" >> $O/stem_u8_phases.txt
 DIRTORCH_AMD_NO_STEM_U8=1 timeout 200 python scripts/exp_stem_u8_time.py 2>&1 | grep -v amdgpu.ids | sed "s/^/generic paired stem  /" >> $O/stem_u8_phases.txt
 cat $O/stem_u8_phases.txt

@@ -331,3 +331,27 @@ def test_in_place_identity_blocks_are_bit_identical(arch, B, H, W, dtype, monkey
     d_pp, f_pp = ref(x), ref.forward_features(x)
     assert torch.equal(d_in, d_pp) and torch.equal(f_in, f_pp), (arch, B, H, W, dtype, sorted(kernels))
     assert torch.isfinite(d_in).all()
+
+
+@pytest.mark.parametrize('stages', [3, 4])
+def test_in_place_identity_blocks_with_paired_weights_beyond_layer1(stages, monkeypatch):
+    """DIRTORCH_AMD_PAIR_STAGES >= 3 moves the paired-weight boundary into layers 3-4, whose identity blocks write in place:
+    there conv3 runs on conv_pair.hip (residual fetched before the K loop, per tile) instead of the kernels the default
+    mode's bit-identity test covers (round-5 advice).  Same gate: in place == ping-pong, bit for bit."""
+    import dir_oracle as O
+    sd = O.synth_state_dict('resnet50', seed=7)
+    g = torch.Generator(device='cuda').manual_seed(19)
+    x = torch.randint(0, 256, (2, 320, 256, 3), generator=g, dtype=torch.uint8, device='cuda')
+    monkeypatch.setenv('DIRTORCH_AMD_PAIR_STAGES', str(stages))
+    monkeypatch.delenv('DIRTORCH_AMD_NO_INPLACE', raising=False)
+    net = make_net('resnet50', {}, sd, 'fp16p')
+    d_in, f_in = net(x).clone(), net.forward_features(x).clone()
+    net.set_profiling(True)
+    net(x)
+    used = {r['name']: r['kernel'] for r in net.get_profile()}
+    assert used.get('layer3.2.conv3', '').startswith('conv_pair<'), used
+    monkeypatch.setenv('DIRTORCH_AMD_NO_INPLACE', '1')
+    ref = make_net('resnet50', {}, sd, 'fp16p')
+    d_pp, f_pp = ref(x), ref.forward_features(x)
+    assert torch.equal(d_in, d_pp) and torch.equal(f_in, f_pp)
+    assert torch.isfinite(d_in).all()

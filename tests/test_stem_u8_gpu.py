@@ -43,7 +43,7 @@ SIZES = [(2, 64, 96), (1, 75, 61), (1, 224, 224), (1, 7, 7), (2, 8, 9), (1, 10, 
 
 
 @pytest.mark.parametrize('B,H,W', SIZES, ids=['%dx%dx%d' % s for s in SIZES])
-def test_stem_pool_u8_vs_fp64_reference(B, H, W):
+def test_stem_pool_u8_vs_fp64_reference(B, H, W, monkeypatch):
     from dirtorch_amd import ops
     u8, w, scale, bias = make_case(31, B, H, W)
     ref = reference_stem(u8, w, scale, bias)
@@ -61,6 +61,11 @@ def test_stem_pool_u8_vs_fp64_reference(B, H, W):
     for seg in (1, 2, 3):
         alt = ops.stem_pool_u8(u8.cuda(), w, scale, bias, MEAN, STD, seg_tiles=seg)
         assert torch.equal(alt[0], base[0]) and torch.equal(alt[1], base[1]), seg
+    # ... nor does the workgroup shape: one 8-wave workgroup per CU on 8 x 32 conv tiles (the default: two 4-wave ones on 4 x 32)
+    monkeypatch.setenv('DIRTORCH_AMD_STEM_U8_WG8', '1')
+    for seg in (0, 1):
+        alt = ops.stem_pool_u8(u8.cuda(), w, scale, bias, MEAN, STD, seg_tiles=seg)
+        assert torch.equal(alt[0], base[0]) and torch.equal(alt[1], base[1]), ('wg8', seg)
 
 
 def test_border_classes_on_a_constant_image():
