@@ -319,7 +319,8 @@ def other_workloads(args, x_bench):
                              'ms_per_step_spread': r['ms_per_step_spread'], 'sim_ms_min_median_max': r['roofline']['launch_ms_min_median_max'],
                              'db_rows_per_sec': r['value'], 'sim_ms': r['roofline']['avg_launch_ms'],
                              'sim_hbm_frac': r['roofline']['frac'], 'sim_kernel': r['roofline']['kernel'], 'rank_ap_ms': r['roofline']['rank_ap_ms'],
-                             'mAP_medium': r['config']['mAP_medium']}
+                             'mAP_medium': r['config']['mAP_medium'], 'whiten_ms': r['roofline'].get('whiten_ms'),
+                             'whiten': r['roofline'].get('whiten')}
             else:
                 out[name] = {'images_per_sec_3scale': r['value'], 'steps': a.steps, 'ms_per_step': r['ms_per_step'],
                              'ms_per_step_spread': r['ms_per_step_spread'], 'batch': a.ms_batch,
@@ -470,6 +471,44 @@ def bench_distractors(args, world, rank, dist):
             t_r.append(c)
         return aps
 
+    # ---- a8 at this scale, outside the timed steps: PCA-whitening the rank's database rows before scoring (test_dir.py:136-138,
+    # common.py:221-239) - synthetic PCA (mean of the rows, orthonormal components, variances over four decades, whitenp 0.25) ----
+    whiten = None
+    if rank == 0 and not getattr(args, 'no_whiten', False):
+        try:
+            nloc = hi - lo
+            mean = local[:8192].mean(dim=0).contiguous()
+            comps = torch.linalg.qr(torch.randn(D, D, device='cuda', generator=gq, dtype=torch.float32))[0].t().contiguous()
+            alpha = (1.0 / torch.logspace(-1, -5, D, device='cuda', dtype=torch.float64).pow(0.25)).float()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def timed(fn, reps):
+                fn()
+                ms = []
+                for _ in range(reps):
+                    e0.record()
+                    out_ = fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms.append(e0.elapsed_time(e1))
+                    del out_
+                return sorted(ms)
+            w_ms = timed(lambda: ops.pca_whiten(local[:nloc], comps, mean, alpha, l2norm=True, unit_range=True), 5)
+            nx = min(nloc, 131072)
+            x_ms = timed(lambda: ops.pca_whiten(local[:nx], comps, mean, alpha, l2norm=True, unit_range=False), 3)
+            fl = 2.0 * nloc * D * D
+            whiten = {'rows': nloc, 'width': D, 'ms': round(w_ms[len(w_ms) // 2], 3), 'ms_min_max': [round(w_ms[0], 3), round(w_ms[-1], 3)],
+                      'kernel': 'whiten_split_kernel (two fp16 planes per operand, 3 plane products) + l2norm_rows_kernel',
+                      'algorithmic_tflops': round(fl / (w_ms[len(w_ms) // 2] * 1e-3) / 1e12, 1),
+                      'frac_of_fp32_mfma_peak_157': round(fl / (w_ms[len(w_ms) // 2] * 1e-3) / 1e12 / 157.0, 3),
+                      'issued_frac_of_fp16_peak': round(3.0 * fl / (w_ms[len(w_ms) // 2] * 1e-3) / 1e12 / PEAK_TFLOPS['fp16'], 3),
+                      'exact_fp32_chain_ms_scaled': round(x_ms[len(x_ms) // 2] * nloc / nx, 2),
+                      'exact_fp32_chain_sample': '%d rows: %.3f ms (gemm_nt_f32, fp32 MFMA) scaled to %d rows' % (nx, x_ms[len(x_ms) // 2], nloc)}
+            del comps, mean, alpha
+        except Exception as e:      # noqa: BLE001 - report and go on: the timed steps below do not depend on it
+            whiten = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     for _ in range(max(Wm, 1)):
         aps = step(False)
     torch.cuda.synchronize()
@@ -518,6 +557,8 @@ def bench_distractors(args, world, rank, dist):
                      'traffic': None, 'avg_launch_ms': round(sim_ms, 4), 'algorithmic_bytes_per_launch': sim_bytes,
                      'launch_ms_min_median_max': [round(min(t_s), 4), round(med(t_s), 4), round(max(t_s), 4)] if t_s else None,
                      'rank_ap_ms': round(r_ms, 4),
+                     # a8 at this scale (outside the timed steps): whitening this rank's rows before they are scored
+                     'whiten': whiten, 'whiten_ms': (whiten or {}).get('ms'),
                      # both layouts of the one exchange step priced side by side (the timed one is `exchange`): bytes each rank
                      # RECEIVES, and what a ring (one xGMI link, ~153 GB/s) / a direct full-mesh all-gather (W - 1 links) needs;
                      # on one GPU they are priced for the 8-GPU node BASELINE configs[3] names

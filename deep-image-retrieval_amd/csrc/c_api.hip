@@ -713,15 +713,44 @@ int dir_fc_l2(const float* x, int B, int K, const float* W, const float* b, int 
     DIR_CATCH
 }
 
-int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components, int v,
-                      const float* scale, int l2norm, float* out, void* stream) {
-    DIR_TRY
+static int pca_whiten_impl(const float* X, int N, int D, const float* mean, const float* components, int v, const float* scale,
+                           int l2norm, float* out, void* stream, bool unit_range) {
     if (N < 0 || D <= 0 || v <= 0) return fail(DIR_ERR_INVALID, "pca_whiten_l2: bad size");
     if (N == 0) return DIR_OK;
     if (!X || !components || !out) return fail(DIR_ERR_INVALID, "pca_whiten_l2: null pointer");
-    int rc = gemm_nt_f32(components, D, X, D, out, v, v, N, D, mean, nullptr, scale, (hipStream_t)stream);
+    int rc = DIR_OK;
+    bool done = false;
+    // Large sets whose operands the caller knows to be bounded (dir_pca_whiten_l2_unit): two fp16 planes per operand, three
+    // plane products on the fp16 matrix cores (sim_split.hip whiten_split) - 8.4 TFLOP of fp32 MFMA chain at config D otherwise
+    if (unit_range && !dir::env().sim_exact && N >= kSimSplitMinRows && whiten_split_admissible(X, D, N, D, v)) {
+        const size_t bytes = whiten_split_workspace_bytes(v, D);
+        void* ws = nullptr;
+        if (hipMallocAsync(&ws, bytes, (hipStream_t)stream) == hipSuccess) {
+            rc = whiten_split(X, D, N, components, D, v, D, mean, scale, out, v, ws, bytes, (hipStream_t)stream);
+            const hipError_t fe = hipFreeAsync(ws, (hipStream_t)stream);
+            if (rc != DIR_OK) return rc;
+            DIR_HIP_CHECK(fe);
+            done = true;
+        } else {
+            (void)hipGetLastError();   // no memory pool / out of memory: the exact chain below needs no scratch
+        }
+    }
+    if (!done) rc = gemm_nt_f32(components, D, X, D, out, v, v, N, D, mean, nullptr, scale, (hipStream_t)stream);
     if (rc != DIR_OK || !l2norm) return rc;
     return l2norm_rows(out, N, v, 1e-12f, (hipStream_t)stream);
+}
+
+int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components, int v,
+                      const float* scale, int l2norm, float* out, void* stream) {
+    DIR_TRY
+    return pca_whiten_impl(X, N, D, mean, components, v, scale, l2norm, out, stream, false);
+    DIR_CATCH
+}
+
+int dir_pca_whiten_l2_unit(const float* X, int N, int D, const float* mean, const float* components, int v,
+                           const float* scale, int l2norm, float* out, void* stream) {
+    DIR_TRY
+    return pca_whiten_impl(X, N, D, mean, components, v, scale, l2norm, out, stream, true);
     DIR_CATCH
 }
 

@@ -55,4 +55,10 @@ bool similarity_split_admissible(const float* P, int ldp, const float* Q, int ld
 int similarity_split(const float* P, int ldp, const float* Q, int ldq, float* out, int ldo, int NP, int NQ, int K,
                      void* workspace, size_t workspace_bytes, hipStream_t stream, bool unit_range = false);
 
+// PCA whitening of a large descriptor set on two fp16 planes per operand (sim_split.hip): out[n][j] = alpha[j] <X[n] - mean, C[j]>
+size_t whiten_split_workspace_bytes(int v, int K);
+bool whiten_split_admissible(const float* X, int ldx, int N, int K, int v);
+int whiten_split(const float* X, int ldx, int N, const float* comps, int ldc, int v, int K, const float* mean, const float* alpha,
+                 float* out, int ldo, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace dir

@@ -383,6 +383,195 @@ __global__ void __launch_bounds__(768) sim_split_lc_kernel(const float* __restri
     }
 }
 
+// ---- PCA whitening of a LARGE descriptor set on the same machinery -------------------------------------------------------
+//   out[n][j] = alpha[j] * sum_k (X[n][k] - mean[k]) * C[j][k]        (dirtorch/utils/common.py:221-232: pca.transform of the
+//                                                                      database before scoring, test_dir.py:136-138)
+// At config D's size (N = 1 006 322, K = v = 2048) this is 8.4 TFLOP: 85 ms on the exact fp32 MFMA chain of gemm_f32.hip
+// (157 TFLOP/s peak), 40x the similarity + ranking step it feeds.  Both operands are bounded - L2-normalised descriptors minus
+// their mean, orthonormal PCA rows - so the PAIR form above applies: two fp16 planes of 2^10 x per operand, three products,
+// fp32 accumulation.  What differs from sim_split_lc_kernel<true>:
+//   * X takes the database's place (streamed once per component block by LDS-DMA as raw fp32, 256 rows per workgroup) and the
+//     mean is subtracted in fp32 right before the split, as the reference subtracts it before its GEMM (no cancellation between
+//     two large dot products); the mean vector lives in LDS (K floats);
+//   * the components take the queries' place (their plane image: split_queries_kernel<true>), 96 rows per block - but there are
+//     v / 96 = 22 blocks, not one, so the grid is 1-D with an XCD-aware decode: the 22 workgroups that share an X tile run on the
+//     SAME XCD at the same time and walk K in the same rotated order - one of them misses to HBM, 21 hit that XCD's L2;
+//   * the result is stored TRANSPOSED, out[n][j] row-major (16-byte stores: a lane holds four consecutive j of one row n),
+//     scaled by 2^-20 alpha[j].
+template <bool HAS_MEAN>
+__global__ void __launch_bounds__(768) whiten_split_kernel(const float* __restrict__ P, int ldp, int NP, int K,
+                                                          const uint16_t* __restrict__ img, const float* __restrict__ mean,
+                                                          const float* __restrict__ alpha, float* __restrict__ out, int ldo,
+                                                          int NQ, int T, int tiles, int qblocks) {
+    constexpr int kSlabQ = dir::kSlabQ2;
+    constexpr int kStage = dir::kStage2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lmean = (float*)(smem + kStages * kStage);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // hardware places block id on XCD id % 8: slot (id / 8) of an XCD = (tile group, component block), blocks fastest
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (slot / qblocks) * 8 + xcd, qb = slot % qblocks;
+    if (tile >= tiles) return;
+    const int i0 = tile * kRowsP;
+    const int rows = min(kRowsP, NP - i0);
+    const int rot = (int)(((unsigned)tile * 7u) % (unsigned)T);
+    if (HAS_MEAN)
+        for (int i = tid; i < K; i += 768) lmean[i] = mean[i];
+
+    if (wave >= 8) {
+        // ================================ loaders (as sim_split_lc_kernel<true>) ================================
+        const int lw = wave - 8;
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(P + (size_t)i0 * ldp), 0, (int)((((size_t)rows - 1) * ldp + K) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)img + (size_t)qb * T * kSlabQ), 0, T * kSlabQ, 0x00020000);
+        uint32_t pvoff[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (lw * 8 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            pvoff[i] = (uint32_t)row * (uint32_t)ldp * 4u + (uint32_t)chunk * 16u;   // rows past `rows`: out of range -> 0
+        }
+        const int q0 = lw * 3;
+        auto issue = [&](int t) __attribute__((always_inline)) {
+            int u = t + rot;
+            u = u >= T ? u - T : u;
+            char* stage = smem + (t % kStages) * kStage;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma16s(rsrc_p, stage + (lw * 8 + i) * 1024, pvoff[i], (uint32_t)u * 128u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                dma16s(rsrc_q, stage + kSlabP + (q0 + i) * 1024, (uint32_t)((q0 + i) * 1024 + lane * 16), (uint32_t)u * kSlabQ);
+        };
+        issue(0);
+        if (T > 1) issue(1);
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T)
+                asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            ring_barrier();   // hand-off t: slab t is complete (and, at t = 0, the mean table); the consumers have left slab t - 1
+            if (t + 2 < T) issue(t + 2);
+        }
+        return;
+    }
+
+    // ==================================== consumers =============================================================
+    const int lrow = lane & 31, lhi = lane >> 5;
+    f32x16_t acc[3], lo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f, lo[j][e] = 0.f;
+    const int boff = (wave * 32 + lrow) * 128, bswz = (lrow >> 1) & 7;
+    const int aoff = kSlabP + lrow * 64, aswz = (lrow >> 2) & 3;
+
+    int cur = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's share of the mean table is written)
+    for (int t = 0; t < T; ++t) {
+        ring_barrier();   // hand-off t (see the loaders)
+        const char* stage = smem + cur * kStage;
+        int u = t + rot;
+        u = u >= T ? u - T : u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c0 = s * 4 + lhi * 2;
+            f32x4_t b0 = *(const f32x4_t*)(stage + boff + ((c0 ^ bswz) << 4));
+            f32x4_t b1 = *(const f32x4_t*)(stage + boff + (((c0 + 1) ^ bswz) << 4));
+            if (HAS_MEAN) {   // k = 32 u + 16 s + 8 lhi + 0..7
+                const f32x4_t m0 = *(const f32x4_t*)(lmean + u * 32 + c0 * 4), m1 = *(const f32x4_t*)(lmean + u * 32 + c0 * 4 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b0[e] -= m0[e], b1[e] -= m1[e];
+            }
+            u32x4_t ah[3], al[3];
+            const int ach = ((s * 2 + lhi) ^ aswz) << 4;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ah[j] = *(const u32x4_t*)(stage + aoff + 0 * kPlane + j * 2048 + ach);
+                al[j] = *(const u32x4_t*)(stage + aoff + 1 * kPlane + j * 2048 + ach);
+            }
+            u32x4_t bh, bl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h, l;
+                const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
+                split2h(x0 * kPairScale, x1 * kPairScale, h, l);
+                bh[e] = h, bl[e] = l;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                lo[j] = FP16::mfma32(__builtin_bit_cast(f16x8_t, al[j]), __builtin_bit_cast(f16x8_t, bh), lo[j]);
+                lo[j] = FP16::mfma32(__builtin_bit_cast(f16x8_t, ah[j]), __builtin_bit_cast(f16x8_t, bl), lo[j]);
+                acc[j] = FP16::mfma32(__builtin_bit_cast(f16x8_t, ah[j]), __builtin_bit_cast(f16x8_t, bh), acc[j]);
+            }
+        }
+        cur = cur + 1 == kStages ? 0 : cur + 1;
+    }
+
+    // D[i][j]: lane holds X row lrow of the strip and component rows i = 32 j + 8 g + 4 lhi + e: four consecutive outputs of row n
+    const int n = i0 + wave * 32 + lrow;
+    if (n < NP) {
+        float* orow = out + (size_t)n * ldo;
+        const bool vec = (ldo & 3) == 0 && (((uintptr_t)out) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q = qb * kQB + j * 32 + 8 * g + 4 * lhi;
+                if (q >= NQ) continue;
+                f32x4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float al_ = (alpha && q + e < NQ) ? alpha[q + e] : 1.f;
+                    v[e] = (acc[j][4 * g + e] + lo[j][4 * g + e]) * (al_ * (1.f / (kPairScale * kPairScale)));
+                }
+                if (vec && q + 3 < NQ) {
+                    *(f32x4_t*)(orow + q) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (q + e < NQ) orow[q + e] = v[e];
+                }
+            }
+    }
+}
+
+size_t whiten_split_workspace_bytes(int v, int K) { return (size_t)ceil_div(v, kQB) * (size_t)ceil_div(K, 32) * kSlabQ2; }
+
+bool whiten_split_admissible(const float* X, int ldx, int N, int K, int v) {
+    return N > 0 && v > 0 && K > 0 && (K % 32) == 0 && (ldx % 4) == 0 && ((uintptr_t)X & 15) == 0 && ldx >= K &&
+           (size_t)ldx * 4 * kRowsP < (1ull << 31) && (size_t)ceil_div(K, 32) * kSlabQ2 < (1ull << 31) &&
+           kLds2 + (size_t)K * 4 <= 160 * 1024 && (size_t)ceil_div(N, kRowsP) * ceil_div(v, kQB) < (1ull << 30);
+}
+
+// X [N, K] (row stride ldx), components [v, K] (row stride ldc), mean [K] or null, alpha [v] or null -> out [N, v] (row stride ldo).
+// Operands must lie in (-64, 64) (X - mean and the components): the caller's promise, as for similarity_split(unit_range = true).
+int whiten_split(const float* X, int ldx, int N, const float* comps, int ldc, int v, int K, const float* mean, const float* alpha,
+                 float* out, int ldo, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!whiten_split_admissible(X, ldx, N, K, v))
+        return fail(DIR_ERR_INVALID, "whiten_split: needs K % 32 == 0, K <= 6144, ldx % 4 == 0 and a 16-byte aligned X");
+    if (ldc < K || ldo < v) return fail(DIR_ERR_INVALID, "whiten_split: ldc >= K and ldo >= v");
+    if (!workspace || workspace_bytes < whiten_split_workspace_bytes(v, K))
+        return fail(DIR_ERR_WORKSPACE, "whiten_split: workspace too small");
+    if (((uintptr_t)workspace & 15) != 0) return fail(DIR_ERR_INVALID, "whiten_split: workspace must be 16-byte aligned");
+    const int T = K / 32, qblocks = ceil_div(v, kQB), tiles = ceil_div(N, kRowsP);
+    const int lds = kLds2 + K * 4;
+    static std::atomic<uint64_t> attr_m{0}, attr_n{0};
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)whiten_split_kernel<true>, 160 * 1024, attr_m));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)whiten_split_kernel<false>, 160 * 1024, attr_n));
+    hipLaunchKernelGGL(split_queries_kernel<true>, dim3(T, qblocks), dim3(256), 0, stream, comps, ldc, v, K, (uint16_t*)workspace);
+    const unsigned grid = (unsigned)(8 * ceil_div(tiles, 8) * qblocks);
+    if (mean)
+        hipLaunchKernelGGL(whiten_split_kernel<true>, dim3(grid), dim3(768), lds, stream, X, ldx, N, K, (const uint16_t*)workspace, mean,
+                           alpha, out, ldo, v, T, tiles, qblocks);
+    else
+        hipLaunchKernelGGL(whiten_split_kernel<false>, dim3(grid), dim3(768), lds, stream, X, ldx, N, K, (const uint16_t*)workspace, mean,
+                           alpha, out, ldo, v, T, tiles, qblocks);
+    DIR_HIP_CHECK(hipGetLastError());
+    return DIR_OK;
+}
+
 size_t similarity_split_workspace_bytes(int NQ, int K) {
     return (size_t)ceil_div(NQ, kQB) * (size_t)ceil_div(K, 32) * kSlabQ;
 }

@@ -29,6 +29,8 @@
 #include "pointwise.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 // Timing-only experiment builds (scripts/exp_abl.sh stem_u8 DIR_STEMU8_ABL <bits>): 1 = no MFMAs / fragment reads,
@@ -160,18 +162,17 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
             decode(d);
         }
     };
+    // this thread carries patch pixel (ppy, ppx) of every tile, both channel halves: two LDS-DMA instructions per tile
+    const int ppy = tid / QW, ppx = tid - ppy * QW;
+    const int ppoff = (ppy * a.W2 + ppx) * 32;
     auto issue_patch = [&](const TileU8& d, char* dst) {
-        const int oy0 = d.c, ox0 = 2 * d.pw0 - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = tid;                   // plane i, patch pixel tid
-            const int py = p / QW, px = p - py * QW;
-            const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
-            const bool ok = p < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
-            const uint32_t v = ok ? (uint32_t)((((d.b * a.H2 + iy) * a.W2 + ix) * 16 + i * 8) * 2) : kOOBu;
-            if (DIR_STEMU8_ABL & 4) continue;
-            dma16u(rsrc_x, dst + (i * NT + wave * 64) * 16, v);
-        }
+        const int iy = d.c - 2 + ppy, ix = 2 * d.pw0 - 3 + ppx;
+        const bool ok = tid < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
+        const int base = ((d.b * a.H2 + d.c - 2) * a.W2 + 2 * d.pw0 - 3) * 32;       // (wave-uniform)
+        const uint32_t v = ok ? (uint32_t)(base + ppoff) : kOOBu;
+        if (DIR_STEMU8_ABL & 4) return;
+        dma16u(rsrc_x, dst + (wave * 64) * 16, v);
+        dma16u(rsrc_x, dst + (NT + wave * 64) * 16, ok ? v + 16 : kOOBu);
     };
 
     TileU8 cur, nxt, pre, prev;
@@ -269,24 +270,10 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         // correction applies) or lies outside the conv map itself (masked out of the max): 13 % of the tiles at 1024^2
         const bool edge = cur.c <= 1 || 2 * (cur.c + TH - 1) + 4 > a.H || cur.pw0 == 0 || 2 * (2 * cur.pw0 + TW - 2) + 4 > a.W;
         f32x16_t acc[2];
-        if (edge) {   // accumulators start at the border-class correction (the folded bias itself is added at the emit)
-            const int cc = border_class(min(max(ox, 0), a.OW - 1), a.W);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int rc = border_class(min(max(oy + j, 0), a.OH - 1), a.H);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4_t c4 = *(const f32x4_t*)(lcorr + (rc * 6 + cc) * 64 + ci * 32 + 8 * g + 4 * lhi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = c4[e];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        }
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;   // (folds into the first MFMA's srcC = 0: no per-tile moves)
         // 20 fragments = patch rows 0..4 of this wave's row pair x 4 s2d columns: patch row q feeds conv row j = 0 through filter
         // row R = q and conv row j = 1 through R = q - 1, so the two rows share 12 of their 16 + 16 fragments.  Fragment of step
         // s + 1 requested before the MFMAs of step s; the pinned read : MFMA interleave keeps hipcc from hoisting every read
@@ -317,15 +304,21 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
 
         // ---- conv outputs outside the conv map -> -inf (edge tiles only; every pool window holds a real output), 3-max
         // along the row in registers: valid in the ODD lanes, window (l - 1, l, l + 1) ---------------------------------
-        if (edge) {
+        if (edge) {   // + the border-class correction of this conv pixel (the folded bias itself is added at the emit)
             const bool col_in = (unsigned)ox < (unsigned)a.OW;
+            const int cc = border_class(min(max(ox, 0), a.OW - 1), a.W);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const bool in = col_in && (unsigned)(oy + j) < (unsigned)a.OH;
+                const int rc = border_class(min(max(oy + j, 0), a.OH - 1), a.H);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float t = acc[j][e];
-                    acc[j][e] = in ? t : -__builtin_inff();
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t c4 = *(const f32x4_t*)(lcorr + (rc * 6 + cc) * 64 + ci * 32 + 8 * g + 4 * lhi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = acc[j][4 * g + e];
+                        acc[j][4 * g + e] = in ? t + c4[e] : -__builtin_inff();
+                    }
                 }
             }
         }
@@ -515,6 +508,14 @@ int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, con
         constexpr int LDS = 3 * 8192 + 2 * 4 * 4096 + 256 + 36 * 64 * 4;
         static std::atomic<uint64_t> attr{0};
         DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_u8_kernel<2>, LDS, attr));
+        static const bool dbg = getenv("DIRTORCH_AMD_DEBUG_OCCUPANCY") != nullptr;   // (read once; a debugging aid, not an A/B switch)
+        static std::atomic<int> told{0};
+        if (dbg && !told.exchange(1)) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)stem_pool_u8_kernel<2>, 256, LDS);
+            fprintf(stderr, "stem_pool_u8_kernel<2>: %d workgroups of 256 threads per CU at %d bytes of LDS (grid %d, %d items)\n", nb, LDS, grid,
+                    a.nitems);
+        }
         hipLaunchKernelGGL(stem_pool_u8_kernel<2>, dim3((unsigned)grid), dim3(256), LDS, stream, a);
     }
     DIR_HIP_CHECK(hipGetLastError());

@@ -465,3 +465,24 @@ def stem_pool_u8(img_u8, w_oihw, bn_scale, bn_bias, mean, std, seg_tiles=0):
     call('dir_stem_pool_u8', ptr(img_u8.contiguous()), ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(sc.data_ptr()),
          ctypes.c_void_p(bi.data_ptr()), m, s, ptr(ws), ptr(y_hi), ptr(y_lo), B, H, W, int(seg_tiles), stream_ptr())
     return y_hi, y_lo
+
+
+def pca_whiten(X, components, mean=None, alpha=None, l2norm=False, eps_unused=None, unit_range=False):
+    """out[n][j] = alpha[j] * <X[n] - mean, components[j]> (+ row L2 normalisation): dir_pca_whiten_l2, the PCA projection of
+    common.whiten_features (dirtorch/utils/common.py:221-239).  unit_range=True (dir_pca_whiten_l2_unit): the caller guarantees
+    |X - mean| < 64 and |components| < 64; sets of >= 32768 rows with a width that is a multiple of 32 then run as two fp16
+    planes per operand on the matrix cores (csrc/sim_split.hip whiten_split_kernel) instead of the exact fp32 MFMA chain."""
+    _need_cuda(X, components, mean, alpha)
+    for t in (X, components, mean, alpha):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise TypeError('contiguous float32 tensors expected')
+    N, D = X.shape
+    v, D2 = components.shape
+    if D != D2:
+        raise ValueError('inner dimensions differ')
+    out = torch.empty(N, v, dtype=torch.float32, device=X.device)
+    if N == 0:
+        return out
+    call('dir_pca_whiten_l2_unit' if unit_range else 'dir_pca_whiten_l2', ptr(X), N, D, ptr(mean), ptr(components), v, ptr(alpha),
+         int(bool(l2norm)), ptr(out), stream_ptr())
+    return out

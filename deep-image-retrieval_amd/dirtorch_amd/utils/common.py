@@ -64,6 +64,9 @@ def l2_normalize(x, eps=1e-12):
     return ops.l2norm_rows_(y, eps).to(dev)
 
 
+WHITEN_SPLIT_MIN_ROWS = 32768     # include/dir_engine.h dir_pca_whiten_l2_unit: below this the exact fp32 chain runs anyway
+
+
 def _transform_dev(pca, X, whitenp, whitenv, whitenm, use_sklearn):
     """Device-side PCA projection; returns (CUDA tensor [N,v], dtype NumPy promotion would give)."""
     res_dtype = np.float32
@@ -79,9 +82,19 @@ def _transform_dev(pca, X, whitenp, whitenv, whitenm, use_sklearn):
         mean = pca['means']
         alpha = None
         res_dtype = np.result_type(np.asarray(X).dtype, comps.dtype)
-    out = ops.gemm_nt(_dev(comps), _dev(X),
-                      qsub=None if mean is None else _dev(np.asarray(mean).reshape(-1)),
-                      alpha=None if alpha is None else _dev(alpha.astype(np.float32)))
+    Xd, Cd = _dev(X), _dev(comps)
+    md = None if mean is None else _dev(np.asarray(mean).reshape(-1))
+    ad = None if alpha is None else _dev(alpha.astype(np.float32))
+    if Xd.shape[0] >= WHITEN_SPLIT_MIN_ROWS and Xd.shape[1] % 32 == 0:
+        # a database-sized set (test_dir.py:136-138 at the 10^6-distractor protocol): when X - mean and the components are
+        # bounded (L2-normalised descriptors, PCA rows) the product runs on two fp16 planes per operand (csrc/sim_split.hip
+        # whiten_split_kernel, ~4x the exact fp32 chain, ~1e-6 of the fp64 result); one abs-max pass over X decides
+        from .. import ranking
+        bound = ranking.UNIT_RANGE_BOUND - (float(md.abs().max()) if md is not None else 0.0)
+        lo, hi = torch.aminmax(Xd)
+        if max(-float(lo), float(hi)) < bound and ranking.is_unit_range(Cd):
+            return ops.pca_whiten(Xd, Cd, md, ad, unit_range=True), res_dtype
+    out = ops.gemm_nt(Cd, Xd, qsub=md, alpha=ad)
     return out, res_dtype
 
 

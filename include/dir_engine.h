@@ -360,6 +360,16 @@ int dir_fc_l2(const float* x, int B, int K, const float* W, const float* b, int 
               void* stream);
 int dir_pca_whiten_l2(const float* X, int N, int D, const float* mean, const float* components,
                       int v, const float* scale, int l2norm, float* out, void* stream);
+/* dir_pca_whiten_l2 for operands the caller KNOWS to be bounded: |X - mean| < 64 and |components| < 64 - L2-normalised descriptors
+ * and the orthonormal rows of a PCA, what common.whiten_features is called on in dirtorch/test_dir.py:136-138.  N >= 32768 with
+ * D % 32 == 0 and D <= 6144 (the 10^6-distractor database of BASELINE configs[3]: 8.4 TFLOP): X minus the mean (subtracted in fp32,
+ * before anything is rounded) and the components as two fp16 planes of 2^10 x each (~22 bits), three plane products on the fp16
+ * matrix cores, fp32 accumulation, result x 2^-20 scale[j] (csrc/sim_split.hip whiten_split_kernel): within ~1e-6 (relative to the
+ * row's largest entry) of the fp64 product, ~4x the fp32 MFMA chain.  A value outside the range overflows its plane and its row
+ * comes out NON-FINITE, never silently wrong.  Other sizes, and DIRTORCH_AMD_SIM_EXACT=1: identical to dir_pca_whiten_l2.
+ * Takes ceil(v/96) * D * 384 bytes of stream-ordered scratch (hipMallocAsync). */
+int dir_pca_whiten_l2_unit(const float* X, int N, int D, const float* mean, const float* components,
+                      int v, const float* scale, int l2norm, float* out, void* stream);
 int dir_similarity(const float* queries, int Q, const float* database, int N, int D, float* scores,
                    void* stream);
 int dir_similarity_unit(const float* queries, int Q, const float* database, int N, int D, float* scores,

@@ -234,7 +234,7 @@ def test_profile_tooling_knows_every_engine_kernel():
                'stem_pool_pair', 'prep_input_pair',                                        # + the paired head's
                'stem_pool_u8', 'prep_input_u8'}                                            # + its uint8-feed form (stem_u8.hip)
     other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_sort_kernel', 'rank_hist_kernel', 'rank_finalize_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
-             'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'sim_split_lc_kernel', 'split_queries_kernel', 'fill_noise_kernel',
+             'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'sim_split_lc_kernel', 'split_queries_kernel', 'whiten_split_kernel', 'fill_noise_kernel',
              'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel'}
     for n in names:
         k = S.bench_kernel_name(S.short(n))
