@@ -416,8 +416,8 @@ __global__ void __launch_bounds__(768) whiten_split_kernel(const float* __restri
     const int i0 = tile * kRowsP;
     const int rows = min(kRowsP, NP - i0);
     const int rot = (int)(((unsigned)tile * 7u) % (unsigned)T);
-    if (HAS_MEAN)
-        for (int i = tid; i < K; i += 768) lmean[i] = mean[i];
+    if (HAS_MEAN)   // the table holds 2^10 mean: (x - mean) 2^10 is then ONE fma per value, bit-identical (a power-of-two scale commutes with rounding)
+        for (int i = tid; i < K; i += 768) lmean[i] = mean[i] * kPairScale;
 
     if (wave >= 8) {
         // ================================ loaders (as sim_split_lc_kernel<true>) ================================
@@ -482,7 +482,10 @@ __global__ void __launch_bounds__(768) whiten_split_kernel(const float* __restri
             if (HAS_MEAN) {   // k = 32 u + 16 s + 8 lhi + 0..7
                 const f32x4_t m0 = *(const f32x4_t*)(lmean + u * 32 + c0 * 4), m1 = *(const f32x4_t*)(lmean + u * 32 + c0 * 4 + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b0[e] -= m0[e], b1[e] -= m1[e];
+                for (int e = 0; e < 4; ++e) b0[e] = __builtin_fmaf(b0[e], kPairScale, -m0[e]), b1[e] = __builtin_fmaf(b1[e], kPairScale, -m1[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b0[e] *= kPairScale, b1[e] *= kPairScale;
             }
             u32x4_t ah[3], al[3];
             const int ach = ((s * 2 + lhi) ^ aswz) << 4;
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(768) whiten_split_kernel(const float* __restri
             for (int e = 0; e < 4; ++e) {
                 uint32_t h, l;
                 const float x0 = e < 2 ? b0[2 * e] : b1[2 * e - 4], x1 = e < 2 ? b0[2 * e + 1] : b1[2 * e - 3];
-                split2h(x0 * kPairScale, x1 * kPairScale, h, l);
+                split2h(x0, x1, h, l);      // (already scaled by 2^10)
                 bh[e] = h, bl[e] = l;
             }
 #pragma unroll
