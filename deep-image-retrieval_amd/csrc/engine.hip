@@ -271,10 +271,6 @@ int dir_engine::finalize(int dt) {
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_bias, L.Cout * 4));
         DIR_HIP_CHECK(hipMemcpy(L.d_bias, bias.data(), L.Cout * 4, hipMemcpyHostToDevice));
         L.tuned.clear();
-        if (L.stem && dt == DIR_FP16P) {
-            const int rc = fold_stem_u8(L, w->data.data(), scale.data(), bias.data());
-            if (rc != DIR_OK) return rc;
-        }
         if (dt == DIR_F32) {
             DIR_HIP_CHECK(hipMalloc((void**)&L.d_wf, packed.size() * 4));
             DIR_HIP_CHECK(hipMemcpy(L.d_wf, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
@@ -292,6 +288,10 @@ int dir_engine::finalize(int dt) {
         }
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed16.size() * 2));
         DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
+        if (L.stem && dt == DIR_FP16P) {   // (after the range check above: a weight the plain form refuses is reported as that layer's)
+            const int rc = fold_stem_u8(L, w->data.data(), scale.data(), bias.data());
+            if (rc != DIR_OK) return rc;
+        }
         if (is_pair[li]) {   // lo plane: what the hi plane's rounding left over, itself rounded to fp16
             std::vector<uint16_t> lo16(packed.size());
             for (size_t i = 0; i < packed.size(); ++i) {

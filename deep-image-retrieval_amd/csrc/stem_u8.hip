@@ -446,7 +446,7 @@ int fold_stem_u8(const float* w, const float* scale, const float* bias, const fl
     for (size_t i = 0; i < packed.size(); ++i) {
         hi[i] = f32_to_f16_bits(packed[i]);
         if ((hi[i] & 0x7c00u) == 0x7c00u && std::isfinite(packed[i]))
-            return fail(DIR_ERR_RANGE, "finalize: a stem weight folded with the image normalisation (" + std::to_string(packed[i]) +
+            return fail(DIR_ERR_RANGE, "finalize: a BatchNorm-folded weight of conv1, folded with the image normalisation (" + std::to_string(packed[i]) +
                                            ") exceeds the fp16 range; use DIR_BF16 or DIR_F32");
         lo[i] = f32_to_f16_bits(packed[i] - f16_bits_to_f32(hi[i]));
     }

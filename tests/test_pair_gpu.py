@@ -358,9 +358,11 @@ def test_fp16p_plumbing(monkeypatch):
     xf = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
     a = net(u8.cuda()).cpu()
     b = net(xf.cuda()).cpu()
-    assert float((a - b).abs().max()) < 2e-6
     ref = O.rmac_forward(sd, 'resnet50', xf).numpy()
     e16p = (1 - O.cosine(b.numpy(), ref)).max()
+    # (round 6: the uint8 feed has its own stem - stem_u8.hip, the image as ONE exact plane - so the two feeds no longer run the
+    # same kernels; they agree to the fp16 noise floor of the layers behind the stem, and both sit on the oracle)
+    assert (1 - O.cosine(a.numpy(), b.numpy())).max() < 5e-5 and (1 - O.cosine(a.numpy(), ref)).max() < 1e-4
     one = net(xf[1:2].cuda()).cpu()
     assert one.shape == (2048,) and float((one - b[1]).abs().max()) < 1e-6
     net.set_profiling(True)

@@ -57,9 +57,9 @@ def test_split_whitening_vs_fp64(N, v):
     print('\n[whiten] %d x %d x %d: max |d| / max|row|  two-plane %.2e   exact fp32 chain %.2e' % (N, D, v, e_split.max(), e_exact.max()))
     assert e_split.max() < 1.5e-6 and e_split.max() < e_exact.max(), (e_split.max(), e_exact.max())
     assert not torch.equal(got, exact)                          # (the two-plane kernel did run: another association of the sum)
-    # rows the reference did not visit: the two device paths agree everywhere
+    # rows the reference did not visit: the two device paths agree everywhere to the sum of their distances from fp64
     d = (got - exact).abs().amax(dim=1) / exact.abs().amax(dim=1)
-    assert float(d.max()) < 2e-6, float(d.max())
+    assert float(d.max()) < 6e-6, float(d.max())
     # with the row normalisation of whiten_features
     gn = ops.pca_whiten(X, comps, mean, alpha, l2norm=True, unit_range=True)[rows].double().cpu().numpy()
     rn = ref / np.linalg.norm(ref, axis=1, keepdims=True)
