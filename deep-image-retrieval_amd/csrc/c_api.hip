@@ -243,9 +243,10 @@ int dir_stem_pool_u8(const void* img_u8, const float* w_oihw, const float* bn_sc
         (void)hipFree(d);
         return fail(DIR_ERR_HIP, std::string("stem_pool_u8 upload: ") + hipGetErrorString(e));
     }
-    rc = prep_input_u8(img_u8, s2d_ws, B, H, W, (hipStream_t)stream);
+    const bool raw = stem_pool_u8_raw_ok(img_u8, B, H, W);
+    rc = raw ? DIR_OK : prep_input_u8(img_u8, s2d_ws, B, H, W, (hipStream_t)stream);
     if (rc == DIR_OK)
-        rc = stem_pool_u8_launch(s2d_ws, d, d + nw, (const float*)(d + 2 * nw), (const float*)(d + 2 * nw + nb), y_hi, y_lo, B, H, W,
+        rc = stem_pool_u8_launch(raw ? img_u8 : nullptr, s2d_ws, d, d + nw, (const float*)(d + 2 * nw), (const float*)(d + 2 * nw + nb), y_hi, y_lo, B, H, W,
                                  (hipStream_t)stream, nullptr, seg_tiles);
     e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d);

@@ -53,6 +53,7 @@ static Env read_env() {
     e.no_inplace = on("DIRTORCH_AMD_NO_INPLACE");
     e.no_stem_u8 = on("DIRTORCH_AMD_NO_STEM_U8");
     e.stem_u8_wg8 = on("DIRTORCH_AMD_STEM_U8_WG8");
+    e.stem_u8_prep = on("DIRTORCH_AMD_STEM_U8_PREP");
     if (const char* s = getenv("DIRTORCH_AMD_STEM_U8_SEG")) e.stem_u8_seg = atoi(s);
     return e;
 }
@@ -388,6 +389,9 @@ int dir_engine::fold_stem_u8(ConvLayer& L, const float* w, const float* scale, c
     std::vector<uint16_t> hi, lo;
     std::vector<float> b2, corr;
     const int rc = dir::fold_stem_u8(w, scale, bias, desc.mean, desc.std, hi, lo, b2, corr);
+    // a preprocess whose 1 / (255 std) pushes a folded weight out of the fp16 range (or a std <= 0) only rules the uint8 stem out:
+    // the tables stay null and dir_forward keeps the generic paired stem (normalisation in prep_input_pair) for that engine
+    if (rc == DIR_ERR_RANGE || rc == DIR_ERR_INVALID) return DIR_OK;
     if (rc != DIR_OK) return rc;
     DIR_HIP_CHECK(hipMalloc((void**)&d_stem_u8_w, hi.size() * 2));
     DIR_HIP_CHECK(hipMemcpy(d_stem_u8_w, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
@@ -709,16 +713,20 @@ int dir_engine::forward_pair_stem(const void* img, int B, int H, int W, int fmt,
     if (img && fmt == DIR_IMG_U8_NHWC && d_stem_u8_w && !sw.no_stem_u8) {
         // the raw uint8 image is exact in ONE fp16 plane: Normalize folded into the filter pair and the bias, two MFMAs per
         // term, pooled in registers (stem_u8.hip)
-        rc = prof_begin("prep_input", "prep_input_u8", 0, (double)B * H * W * 3 + (double)B * p.H2 * p.W2 * 32, stream);
-        if (rc != DIR_OK) return rc;
-        rc = prep_input_u8(img, s2d, B, H, W, stream);
-        if (rc != DIR_OK) return rc;
-        if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        const bool raw = stem_pool_u8_raw_ok(img, B, H, W);   // the stem reads the image itself: no prep launch, no s2d plane
+        if (!raw) {
+            rc = prof_begin("prep_input", "prep_input_u8", 0, (double)B * H * W * 3 + (double)B * p.H2 * p.W2 * 32, stream);
+            if (rc != DIR_OK) return rc;
+            rc = prep_input_u8(img, s2d, B, H, W, stream);
+            if (rc != DIR_OK) return rc;
+            if ((rc = prof_end(stream)) != DIR_OK) return rc;
+        }
         rc = prof_begin("conv1+maxpool", "stem_pool_u8", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
-                        2.0 * (double)B * p.H2 * p.W2 * 16 + 4.0 * ((double)B * p.PH * p.PW * 64 + 64 * 256), stream);
+                        (raw ? (double)B * H * W * 3 : 2.0 * (double)B * p.H2 * p.W2 * 16) + 4.0 * ((double)B * p.PH * p.PW * 64 + 64 * 256),
+                        stream);
         if (rc != DIR_OK) return rc;
-        rc = stem_pool_u8_launch(s2d, d_stem_u8_w, d_stem_u8_w_lo, d_stem_u8_bias, d_stem_u8_corr, (uint16_t*)(base + p.bufA),
-                                 (uint16_t*)(base + p.lo_stem), B, H, W, stream, d_ovf, sw.stem_u8_seg);
+        rc = stem_pool_u8_launch(raw ? img : nullptr, s2d, d_stem_u8_w, d_stem_u8_w_lo, d_stem_u8_bias, d_stem_u8_corr,
+                                 (uint16_t*)(base + p.bufA), (uint16_t*)(base + p.lo_stem), B, H, W, stream, d_ovf, sw.stem_u8_seg);
         if (rc != DIR_OK) return rc;
         return prof_end(stream);
     }

@@ -32,8 +32,10 @@ int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_
 int fold_stem_u8(const float* w, const float* scale, const float* bias, const float* mean3, const float* std3,
                  std::vector<uint16_t>& hi, std::vector<uint16_t>& lo, std::vector<float>& b2, std::vector<float>& corr);
 int prep_input_u8(const void* img, void* out, int B, int H, int W, hipStream_t stream);
-int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, const float* bias, const float* corr, void* y_hi,
-                        void* y_lo, int B, int H, int W, hipStream_t stream, int* ovf = nullptr, int seg_tiles = 0);
+// img: the uint8 NHWC image (RAW form when stem_pool_u8_raw_ok: no prep launch, s2d may be null) or null (s2d = prep_input_u8's plane)
+bool stem_pool_u8_raw_ok(const void* img, int B, int H, int W);
+int stem_pool_u8_launch(const void* img, const void* s2d, const void* w_hi, const void* w_lo, const float* bias, const float* corr,
+                        void* y_hi, void* y_lo, int B, int H, int W, hipStream_t stream, int* ovf = nullptr, int seg_tiles = 0);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
 int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* pscores, const int* pos_off,

@@ -62,6 +62,8 @@ __device__ __forceinline__ float lane_right(float v) {
 }
 
 struct StemU8Args {
+    const uint8_t* img;         // RAW form: the uint8 NHWC image itself [B, H, W, 3] (W even)
+    uint32_t img_bytes;
     const uint16_t* x;          // s2d plane [B, H2, W2, 16], u / 256
     const uint16_t *wh, *wl;    // folded filter pair [64][4][4][16]
     const float* bias;          // [64] folded bias (all 147 taps inside the image); added - with the ReLU - to the POOLED values
@@ -92,7 +94,11 @@ __device__ __forceinline__ int border_class(int o, int n) {
 // NRP = conv row PAIRS per workgroup (= pooled rows per tile): 4 -> 8 waves, 8 x 32 conv tiles, one workgroup per CU;
 // 2 -> 4 waves, 4 x 32 conv tiles, TWO workgroups per CU - their barriers are independent, so one's matrix phase runs
 // under the other's pooling / emit phase on the same SIMDs (the phases of one workgroup's waves move in lock-step).
-template <int NRP>
+// RAW: the patch comes straight from the uint8 NHWC image - every thread fetches the 2 x 6 bytes of ITS space-to-depth pixel two
+// tiles ahead (six 2-byte buffer loads into registers; needs an even W: rows of 3 W bytes then keep 6-byte groups 2-byte aligned),
+// converts them to u / 256 one tile later and writes the two 16-byte plane chunks the MFMA fragments read - prep_input_u8's
+// arithmetic, without the launch, without the 32-bytes-per-pixel plane in HBM (3 bytes per image pixel in instead of 8 + 8 out + in).
+template <int NRP, bool RAW>
 __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kernel(const StemU8Args a) {
     typedef FP16 DT;
     typedef DT::frag_t frag_t;
@@ -118,7 +124,8 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     const int lrow = lane & 31, lhi = lane >> 5;
     const int ci = wave & 1, rp = wave >> 1;     // channel tile, conv row pair
 
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = RAW ? __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, a.img_bytes, 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
 
     // ---- the filter pair of this wave's channel tile, straight in MFMA operand layout (128 VGPRs, fetched once) ----------
     frag_t wfh[4][4], wfl[4][4];
@@ -175,6 +182,36 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         dma16u(rsrc_x, dst + (NT + wave * 64) * 16, ok ? v + 16 : kOOBu);
     };
 
+    // RAW: the 12 image bytes of this thread's patch pixel, as six zero-extended 16-bit loads (bytes 2k, 2k + 1 of row 0, then row 1)
+    uint32_t rw[6] = {0, 0, 0, 0, 0, 0};
+    auto load_raw = [&](const TileU8& d) {
+        const int iy = d.c - 2 + ppy, ix = 2 * d.pw0 - 3 + ppx;
+        const bool ok = tid < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
+        const uint32_t o0 = ok ? (uint32_t)(((d.b * a.H + 2 * iy) * a.W + 2 * ix) * 3) : kOOBu;      // offsets >= 2^31 read as 0
+        const uint32_t o1 = (ok && 2 * iy + 1 < a.H) ? o0 + (uint32_t)(a.W * 3) : kOOBu;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rw[k] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_x, o0 + 2 * k, 0, 0);
+            rw[3 + k] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_x, o1 + 2 * k, 0, 0);
+        }
+    };
+    auto store_raw = [&](char* dst) {   // channel (dy * 2 + dx) * 3 + c = byte 6 dy + 3 dx + c of the twelve; u / 256 is exact in fp16
+        float f[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            f[2 * k] = (float)(rw[k] & 0xffu) * 0.00390625f;
+            f[2 * k + 1] = (float)((rw[k] >> 8) & 0xffu) * 0.00390625f;
+        }
+        u32x4_t p0, p1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p0[e] = FP16::pack(f[2 * e], f[2 * e + 1]);
+        p1[0] = FP16::pack(f[8], f[9]);
+        p1[1] = FP16::pack(f[10], f[11]);
+        p1[2] = p1[3] = 0;
+        *(u32x4_t*)(dst + tid * 16) = p0;
+        *(u32x4_t*)(dst + (NT + tid) * 16) = p1;
+    };
+
     TileU8 cur, nxt, pre, prev;
     cur.item = blockIdx.x;
     cur.t = 0;
@@ -196,21 +233,34 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
             asm volatile("" : "+v"(wfh[R][ks]));
             asm volatile("" : "+v"(wfl[R][ks]));
         }
-    issue_patch(cur, smem);
-    if (nxt.valid) issue_patch(nxt, smem + PATCH);
+    if (RAW) {   // patch 0 into its buffer, patch 1 into the registers (phase 0 stores it)
+        load_raw(cur);
+        store_raw(smem);
+        if (nxt.valid) load_raw(nxt);
+    } else {
+        issue_patch(cur, smem);
+        if (nxt.valid) issue_patch(nxt, smem + PATCH);
+    }
 
     // phase n: [wait patch n | barrier] issue patch n + 2 -> emit the pooled rows of tile n - 1 -> multiply tile n -> pool in
     // registers -> publish the rows other waves / the next tile finish.  The last phase only emits.
     int pb = 0;       // patch buffer of `cur` (n % 3)
     int xb = 0;       // exchange buffer `cur` publishes into (n & 1)
     for (;;) {
-        if (nxt.valid)
+        if (RAW)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (patch n was WRITTEN by this workgroup's own ds_writes in phase n - 1)
+        else if (nxt.valid)
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // patch n landed; the 2 DMA ops of patch n + 1 may fly
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         ring_barrier();   // patch n visible; rows published in phase n - 1 visible; phase n - 1's LDS reads retired everywhere
 
-        if (pre.valid) {  // buffer (n + 2) % 3 = (n - 1) % 3 was last read by the MFMAs of phase n - 1
+        if (RAW) {
+            // the registers hold patch n + 1 (fetched in phase n - 1): into buffer (n + 1) % 3, which the MFMAs of phase n - 2 read
+            // last; then the fetch of patch n + 2 goes out, a whole phase ahead of its conversion
+            if (nxt.valid) store_raw(smem + (pb == 2 ? 0 : pb + 1) * PATCH);
+            if (pre.valid) load_raw(pre);
+        } else if (pre.valid) {  // buffer (n + 2) % 3 = (n - 1) % 3 was last read by the MFMAs of phase n - 1
             const int nb = pb == 0 ? 2 : pb - 1;
             issue_patch(pre, smem + nb * PATCH);
         }
@@ -463,11 +513,21 @@ int prep_input_u8(const void* img, void* out, int B, int H, int W, hipStream_t s
     return DIR_OK;
 }
 
-int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, const float* bias, const float* corr, void* y_hi,
-                        void* y_lo, int B, int H, int W, hipStream_t stream, int* ovf, int seg_tiles) {
-    if (!s2d || !w_hi || !w_lo || !bias || !corr || !y_hi || !y_lo) return fail(DIR_ERR_INVALID, "stem_pool_u8: null pointer");
+// The RAW form (no prep_input_u8 launch, no space-to-depth plane) applies when the image rows keep 6-byte groups 2-byte aligned
+// and the 32-bit buffer offsets reach every byte; DIRTORCH_AMD_STEM_U8_PREP / _WG8 keep the two-kernel form for A/B.
+bool stem_pool_u8_raw_ok(const void* img, int B, int H, int W) {
+    return img && (W % 2) == 0 && ((uintptr_t)img & 1) == 0 && (size_t)B * H * W * 3 < (1ull << 31) && !env().stem_u8_prep &&
+           !env().stem_u8_wg8;
+}
+
+int stem_pool_u8_launch(const void* img, const void* s2d, const void* w_hi, const void* w_lo, const float* bias, const float* corr,
+                        void* y_hi, void* y_lo, int B, int H, int W, hipStream_t stream, int* ovf, int seg_tiles) {
+    const bool raw = stem_pool_u8_raw_ok(img, B, H, W);
+    if ((!raw && !s2d) || !w_hi || !w_lo || !bias || !corr || !y_hi || !y_lo) return fail(DIR_ERR_INVALID, "stem_pool_u8: null pointer");
     if (H < 7 || W < 7) return fail(DIR_ERR_INVALID, "stem_pool_u8: image smaller than the 7x7 stem");
     StemU8Args a;
+    a.img = (const uint8_t*)img;
+    a.img_bytes = raw ? (uint32_t)((size_t)B * H * W * 3) : 0;
     a.x = (const uint16_t*)s2d;
     a.wh = (const uint16_t*)w_hi;
     a.wl = (const uint16_t*)w_lo;
@@ -482,9 +542,9 @@ int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, con
     a.OW = (W - 1) / 2 + 1;
     a.PH = (a.OH - 1) / 2 + 1;
     a.PW = (a.OW - 1) / 2 + 1;
-    if ((size_t)B * a.H2 * a.W2 * 32 >= (1ull << 31))
+    if (!raw && (size_t)B * a.H2 * a.W2 * 32 >= (1ull << 31))
         return fail(DIR_ERR_INVALID, "stem_pool_u8: input exceeds 2^31 bytes; lower the batch");
-    a.x_bytes = (uint32_t)((size_t)B * a.H2 * a.W2 * 32);
+    a.x_bytes = raw ? 0 : (uint32_t)((size_t)B * a.H2 * a.W2 * 32);
     a.tiles_x = (a.PW + 14) / 15;
     // NRP = 2 (two 4-wave workgroups per CU) unless DIRTORCH_AMD_STEM_U8_WG8 asks for the one-workgroup form.
     // Segment length: seg_rows = 2 T' - 1 pooled rows are exactly T' tiles of TH conv rows (no wasted row); 31 unless that leaves
@@ -502,21 +562,26 @@ int stem_pool_u8_launch(const void* s2d, const void* w_hi, const void* w_lo, con
     if (wg8) {
         constexpr int LDS = 3 * 16384 + 2 * 8 * 4096 + 256 + 36 * 64 * 4;
         static std::atomic<uint64_t> attr{0};
-        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_u8_kernel<4>, LDS, attr));
-        hipLaunchKernelGGL(stem_pool_u8_kernel<4>, dim3((unsigned)grid), dim3(512), LDS, stream, a);
+        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)(stem_pool_u8_kernel<4, false>), LDS, attr));
+        hipLaunchKernelGGL((stem_pool_u8_kernel<4, false>), dim3((unsigned)grid), dim3(512), LDS, stream, a);
     } else {
         constexpr int LDS = 3 * 8192 + 2 * 4 * 4096 + 256 + 36 * 64 * 4;
         static std::atomic<uint64_t> attr{0};
-        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)stem_pool_u8_kernel<2>, LDS, attr));
+        static std::atomic<uint64_t> attr_raw{0};
+        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)(stem_pool_u8_kernel<2, false>), LDS, attr));
+        DIR_HIP_CHECK(ensure_dynamic_lds((const void*)(stem_pool_u8_kernel<2, true>), LDS, attr_raw));
         static const bool dbg = getenv("DIRTORCH_AMD_DEBUG_OCCUPANCY") != nullptr;   // (read once; a debugging aid, not an A/B switch)
         static std::atomic<int> told{0};
         if (dbg && !told.exchange(1)) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)stem_pool_u8_kernel<2>, 256, LDS);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)(stem_pool_u8_kernel<2, true>), 256, LDS);
             fprintf(stderr, "stem_pool_u8_kernel<2>: %d workgroups of 256 threads per CU at %d bytes of LDS (grid %d, %d items)\n", nb, LDS, grid,
                     a.nitems);
         }
-        hipLaunchKernelGGL(stem_pool_u8_kernel<2>, dim3((unsigned)grid), dim3(256), LDS, stream, a);
+        if (raw)
+            hipLaunchKernelGGL((stem_pool_u8_kernel<2, true>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
+        else
+            hipLaunchKernelGGL((stem_pool_u8_kernel<2, false>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
     }
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;

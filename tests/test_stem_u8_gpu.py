@@ -39,7 +39,8 @@ def make_case(seed, B, H, W, flat=False):
     return u8, w, scale, bias
 
 
-SIZES = [(2, 64, 96), (1, 75, 61), (1, 224, 224), (1, 7, 7), (2, 8, 9), (1, 10, 33), (3, 300, 130), (1, 513, 767)]
+# (even widths take the RAW form - the stem reads the image bytes itself -, odd ones the prep_input_u8 plane; odd heights both)
+SIZES = [(2, 64, 96), (1, 75, 61), (1, 224, 224), (1, 7, 7), (2, 8, 9), (1, 10, 33), (3, 300, 130), (1, 513, 767), (2, 61, 76), (1, 7, 8), (2, 513, 640)]
 
 
 @pytest.mark.parametrize('B,H,W', SIZES, ids=['%dx%dx%d' % s for s in SIZES])
@@ -61,6 +62,12 @@ def test_stem_pool_u8_vs_fp64_reference(B, H, W, monkeypatch):
     for seg in (1, 2, 3):
         alt = ops.stem_pool_u8(u8.cuda(), w, scale, bias, MEAN, STD, seg_tiles=seg)
         assert torch.equal(alt[0], base[0]) and torch.equal(alt[1], base[1]), seg
+    # ... nor where the patch comes from: the two-kernel form (prep_input_u8 writes the u / 256 plane, the stem reads it by LDS-DMA)
+    # against the default for an even W, where the stem converts the image bytes itself
+    monkeypatch.setenv('DIRTORCH_AMD_STEM_U8_PREP', '1')
+    alt = ops.stem_pool_u8(u8.cuda(), w, scale, bias, MEAN, STD)
+    assert torch.equal(alt[0], base[0]) and torch.equal(alt[1], base[1]), 'prep'
+    monkeypatch.delenv('DIRTORCH_AMD_STEM_U8_PREP')
     # ... nor does the workgroup shape: one 8-wave workgroup per CU on 8 x 32 conv tiles (the default: two 4-wave ones on 4 x 32)
     monkeypatch.setenv('DIRTORCH_AMD_STEM_U8_WG8', '1')
     for seg in (0, 1):
@@ -121,7 +128,8 @@ def test_engine_uint8_feed_fp16p_vs_fp32_feed_and_oracle(arch, B, H, W):
     a = net(u8.cuda()).cpu().numpy().reshape(B, -1)
     used = {r['name']: r['kernel'] for r in net.get_profile()}
     net.set_profiling(False)
-    assert used.get('conv1+maxpool') == 'stem_pool_u8' and used.get('prep_input') == 'prep_input_u8', used
+    # (an even width: the stem reads the image itself, there is no prep launch; an odd one: prep_input_u8 + the stem)
+    assert used.get('conv1+maxpool') == 'stem_pool_u8' and used.get('prep_input') == (None if W % 2 == 0 else 'prep_input_u8'), used
     b = net(xf.cuda()).cpu().numpy().reshape(B, -1)
     ref = O.rmac_forward(sd, arch, xf).numpy().reshape(B, -1)
     e_ab, e_a, e_b = 1 - O.cosine(a, b), 1 - O.cosine(a, ref), 1 - O.cosine(b, ref)
