@@ -789,10 +789,13 @@ def main():
                          "Normalize on the device inside the step - the feed the drop-in CLIs use (utils/pytorch_loader.py) and the "
                          "reference's real input (transforms.py:617-623); 'f32' = the normalised fp32 NCHW tensor the reference's "
                          "net(x) takes (rounds 1-5).  The other feed's rate rides along as config.<feed>_feed_images_per_sec")
-    ap.add_argument('--checkpoint', default='calibrated', choices=['calibrated', 'he'],
-                    help="weights of the timed step: 'calibrated' (default since round 6) = the BatchNorm-calibrated synthetic checkpoint "
-                         "the parity numbers are quoted on (one fp32 CPU forward of two images before the clock starts), 'he' = the "
-                         "plain He-init checkpoint of rounds 1-5; the other one's rate rides along as config.he_init_images_per_sec")
+    ap.add_argument('--checkpoint', default='he', choices=['calibrated', 'he'],
+                    help="weights of the timed step: 'he' (default) = the random-init (He-normal) checkpoint of tests/synth.py, as in rounds "
+                         "1-5 and as the bench contract words it; 'calibrated' = the same weights with BatchNorm statistics calibrated on "
+                         "synthetic images - the conditioned network the parity numbers (config.one_minus_cos) are quoted on (one fp32 CPU "
+                         "forward of two images before the clock starts).  Since round 6 the OTHER checkpoint's rate of the same step rides "
+                         "along as config.calibrated_images_per_sec / config.he_init_images_per_sec, with the dominant kernel's launch "
+                         "average on its activations (the 3x3 kernels are power-bound and data-dependent: ~4 % between the two)")
     ap.add_argument('--autotune', action='store_true',
                     help='time every admissible tile variant per layer first (default: the built-in tile heuristic, '
                          'which the tuner no longer beats at this shape)')
@@ -1005,21 +1008,38 @@ def main():
                     name, kern, ms, fl / ms / 1e9, by / ms / 1e6), file=sys.stderr)
         cpu, precision, workloads = None, None, None
         side = {}
+        sd_cal = sd_timed if args.checkpoint == 'calibrated' else None
         if world == 1:
-            # the same step on the OTHER feed and on the OTHER checkpoint (20 steps each, median over groups of 5)
+            # the same step on the OTHER feed and on the OTHER checkpoint (20 steps each, median over groups of 5; the dominant
+            # kernel's average launch from the profile records of 4 more steps)
             other_x = x_f32 if args.input == 'u8' else x_u8
             med, lo_, hi_ = grouped_rate(lambda: net(other_x), B)
             side['%s_feed_images_per_sec' % ('fp32' if args.input == 'u8' else 'u8')] = med
             side['%s_feed_min_max' % ('fp32' if args.input == 'u8' else 'u8')] = [lo_, hi_]
-            net2 = nets.create_model(args.arch + '_rmac', pretrained='')
-            net2.load_state_dict(bench_state_dict(args.arch, S, 'he') if args.checkpoint == 'calibrated' else sd_timed)
-            net2.compute_dtype = args.dtype
-            net2.cuda().eval()
-            if args.checkpoint == 'calibrated':
+            del other_x
+            other_kind = 'he' if args.checkpoint == 'calibrated' else 'calibrated'
+            if other_kind == 'he' or args.cpu_seconds > 0:       # (calibrating costs one fp32 CPU forward of two images)
+                sd_other = bench_state_dict(args.arch, S, other_kind)
+                if other_kind == 'calibrated':
+                    sd_cal = sd_other
+                net2 = nets.create_model(args.arch + '_rmac', pretrained='')
+                net2.load_state_dict(sd_other)
+                net2.compute_dtype = args.dtype
+                net2.cuda().eval()
                 med, lo_, hi_ = grouped_rate(lambda: net2(x), B)
-                side['he_init_images_per_sec'] = med
-                side['he_init_min_max'] = [lo_, hi_]
-            del net2, other_x
+                tag = 'he_init' if other_kind == 'he' else 'calibrated'
+                side[tag + '_images_per_sec'] = med
+                side[tag + '_min_max'] = [lo_, hi_]
+                net2.set_profiling(1024)
+                for _ in range(4):
+                    net2(x)
+                torch.cuda.synchronize()
+                doms = [r['ms'] for r in net2.get_profile() if r['kernel'] == dom]
+                net2.set_profiling(False)
+                if doms:       # the dominant kernel is power-bound and data-dependent: its launch average on the other checkpoint's activations
+                    side[tag + '_dominant_kernel_avg_launch_ms'] = round(sum(doms) / len(doms), 5)
+                    side[tag + '_dominant_kernel_frac'] = round(dfl / dn / (sum(doms) / len(doms) * 1e-3) / 1e12 / peak_tf, 4) if not hbm_bound else None
+                del net2
         del x_f32, x_u8
         if world == 1 and args.cpu_seconds > 0:
             del shard
@@ -1029,7 +1049,7 @@ def main():
                 cpu, _ = cpu_baseline(args.arch, S, args.cpu_seconds)
             else:
                 precision, cpu = precision_leg(args.arch, S, B, x, args.cpu_seconds, args.dtype, feed=args.input,
-                                               sd_cal=sd_timed if args.checkpoint == 'calibrated' else None, sd_rate=sd_timed)
+                                               sd_cal=sd_cal, sd_rate=sd_timed)
             if not args.no_workloads:
                 workloads = other_workloads(args, x)
         value = world * B * K / el
@@ -1044,7 +1064,9 @@ def main():
                        'input': ('uint8 NHWC images resident in HBM; ToTensor + Normalize on the device inside the step (the drop-in '
                                  'CLIs\' feed, transforms.py:617-623)' if args.input == 'u8' else 'fp32 NCHW (normalised) resident in HBM'),
                        'timed_checkpoint': ('BatchNorm-calibrated synthetic (tests/synth.py; the checkpoint one_minus_cos is quoted on)'
-                                            if args.checkpoint == 'calibrated' else 'He-init synthetic (tests/synth.py)'),
+                                            if args.checkpoint == 'calibrated' else
+                                            'random-init (He-normal) synthetic (tests/synth.py), as rounds 1-5; the BatchNorm-calibrated one, on which '
+                                            'one_minus_cos is quoted, is timed beside it: calibrated_images_per_sec'),
                        **side,
                        'gflop_per_image': GFLOP_PER_IMG.get((args.arch, S)),
                        # ---- parity of THIS line's dtype as flat scalars (measured in this run, outside the timed region):
