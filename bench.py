@@ -726,28 +726,49 @@ def self_spawn(n, argv, dry=False):
         if have < n:
             print('bench.py --gpus %d needs %d GPUs, found %d' % (n, n, have), file=sys.stderr)
             return 2
-    with socket.socket() as so:
-        so.bind(('127.0.0.1', 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    # wait for all ranks; when one fails, the others would sit in a collective forever: stop exactly the processes started here
-    rc, live = 0, list(procs)
-    while live:
-        time.sleep(0.2)
-        for pr in list(live):
-            code = pr.poll()
-            if code is None:
-                continue
-            live.remove(pr)
-            if code != 0 and rc == 0:
-                rc = code
-                for other in live:
-                    other.terminate()
+    def launch():
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        ps = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (the pool's driver needs dmabuf IPC; a user's own setting wins)
+            ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                       stdout=None if r == 0 else subprocess.DEVNULL))
+        return ps
+    # wait for all ranks; when one fails, the others would sit in a collective forever: stop exactly the processes started here.
+    # The port is found by bind(0) + close, so another process can take it before rank 0 binds it: ranks that all die within the
+    # first seconds are relaunched on a new port (twice at most); an interrupted launcher takes its ranks with it.
+    rc = 0
+    for attempt in range(3):
+        procs = launch()
+        t_start = time.perf_counter()
+        rc, live = 0, list(procs)
+        try:
+            while live:
+                time.sleep(0.2)
+                for pr in list(live):
+                    code = pr.poll()
+                    if code is None:
+                        continue
+                    live.remove(pr)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        for other in live:
+                            other.terminate()
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.terminate()
+            for pr in procs:
+                try:
+                    pr.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+        if rc == 0 or time.perf_counter() - t_start > 20:      # (a rendezvous that lost its port fails at once; anything later is real)
+            break
     return rc
 
 
