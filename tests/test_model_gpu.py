@@ -97,7 +97,7 @@ def test_batch_composition_is_irrelevant():
         assert float((one - full[i]).abs().max()) < 2e-4, i
 
 
-@pytest.mark.parametrize('dtype', ['fp16', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp16', 'bf16', 'fp16p'])     # (fp16p on this uint8 feed: stem_u8.hip's hand-written waits under overlap)
 def test_forwards_overlapping_on_streams_are_bit_identical(dtype):
     """The batch-1 extraction loop issues forwards round-robin on a few HIP streams (test_dir.StreamPool: one 1024^2
     image cannot fill 256 CUs).  Every trunk map must equal the single-stream one bit for bit - the same kernels run on
