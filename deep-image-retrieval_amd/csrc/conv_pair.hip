@@ -1015,6 +1015,10 @@ int stem_pool_pair_launch(const void* s2d_hi, const void* s2d_lo, const void* w_
     a.ovf = ovf;
     const long blocks = (long)B * ((a.PH + 2) / 3) * ((a.PW + 14) / 15);
     const bool v1 = env().stem_v1;   // A/B and bisecting (dir_reload_env after flipping it)
+    // round 6, the default: stem_u8.hip's kernel structure on pairs (tiles walk down column strips, the max-pool runs in registers,
+    // two 4-wave workgroups per CU; same sums in the same order - bit-identical); DIRTORCH_AMD_STEM_PAIR_OLD keeps the form below
+    if (!v1 && !env().stem_pair_old)
+        return stem_pool_pair_walk_launch(s2d_hi, s2d_lo, w_hi, w_lo, bias, y_hi, y_lo, B, H2, W2, OH, OW, stream, ovf);
     if (!v1) {
         constexpr int LDSP = 2 * 2 * 2 * 512 * 16 + 8 * 32 * 256 + 256;   // two patch pairs + the fp32 conv tile + bias
         static std::atomic<uint64_t> attr_p{0};

@@ -55,6 +55,7 @@ struct Env {
     bool experiments = false;                    // ..._EXPERIMENTS: opt-in kernels of an experiments build (conv_ring / conv_seam3)
     bool no_inplace = false;                     // ..._NO_INPLACE: layers 3-4's identity blocks ping-pong again instead of writing their output in place
     bool no_stem_u8 = false;                     // ..._NO_STEM_U8: DIR_FP16P on the uint8 feed takes the generic paired stem (image pair, three MFMAs per term) again
+    bool stem_pair_old = false;                  // ..._STEM_PAIR_OLD: the generic paired stem as conv_pair.hip's stem_pool_pair_persist_kernel (3 x 15 pooled tiles through a 64 KB fp32 conv tile)
     bool stem_u8_prep = false;                   // ..._STEM_U8_PREP: stem_u8.hip reads prep_input_u8's space-to-depth plane again instead of the raw image
     bool stem_u8_wg8 = false;                    // ..._STEM_U8_WG8: stem_u8.hip as ONE 8-wave workgroup per CU (8 x 32 conv tiles) instead of two 4-wave ones
     int stem_u8_seg = 0;                         // ..._STEM_U8_SEG = T: stem_u8.hip walks segments of T tiles (4 T - 1 pooled rows); 0 = its own choice, 1 = independent tiles

@@ -54,6 +54,7 @@ static Env read_env() {
     e.no_stem_u8 = on("DIRTORCH_AMD_NO_STEM_U8");
     e.stem_u8_wg8 = on("DIRTORCH_AMD_STEM_U8_WG8");
     e.stem_u8_prep = on("DIRTORCH_AMD_STEM_U8_PREP");
+    e.stem_pair_old = on("DIRTORCH_AMD_STEM_PAIR_OLD");
     if (const char* s = getenv("DIRTORCH_AMD_STEM_U8_SEG")) e.stem_u8_seg = atoi(s);
     return e;
 }

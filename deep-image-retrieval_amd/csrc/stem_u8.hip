@@ -64,7 +64,8 @@ __device__ __forceinline__ float lane_right(float v) {
 struct StemU8Args {
     const uint8_t* img;         // RAW form: the uint8 NHWC image itself [B, H, W, 3] (W even)
     uint32_t img_bytes;
-    const uint16_t* x;          // s2d plane [B, H2, W2, 16], u / 256
+    const uint16_t* x;          // s2d plane [B, H2, W2, 16], u / 256 (XPAIR: the hi plane of the normalised image pair)
+    const uint16_t* xl;         // XPAIR: its lo plane
     const uint16_t *wh, *wl;    // folded filter pair [64][4][4][16]
     const float* bias;          // [64] folded bias (all 147 taps inside the image); added - with the ReLU - to the POOLED values
     const float* corr;          // [6][6][64] border-class corrections (class 0 = interior = zeros)
@@ -98,8 +99,15 @@ __device__ __forceinline__ int border_class(int o, int n) {
 // tiles ahead (six 2-byte buffer loads into registers; needs an even W: rows of 3 W bytes then keep 6-byte groups 2-byte aligned),
 // converts them to u / 256 one tile later and writes the two 16-byte plane chunks the MFMA fragments read - prep_input_u8's
 // arithmetic, without the launch, without the 32-bytes-per-pixel plane in HBM (3 bytes per image pixel in instead of 8 + 8 out + in).
-template <int NRP, bool RAW>
+// XPAIR (never with RAW): the generic paired stem of DIR_FP16P on this kernel's structure - the image is an fp16 PAIR (any fp32
+// input: the reference's normalised tensor, prep_input_pair's two planes), nothing is folded (a.bias is bn1's, there is no border
+// table: zero padding of a normalised image is the plain OOB zero), every term is three MFMAs in conv_pair.hip's order
+// (w_hi.x_hi, w_hi.x_lo, w_lo.x_hi) from accumulators that START at the bias - the sums stem_pool_pair_persist_kernel forms, bit for
+// bit - and the patch pair is double-buffered with the next tile's four DMA pieces issued one phase ahead (2 x 16 + 32 KB: two
+// workgroups per CU).
+template <int NRP, bool RAW, bool XPAIR = false>
 __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kernel(const StemU8Args a) {
+    static_assert(!(RAW && XPAIR), "the raw-image form is the uint8 feed's");
     typedef FP16 DT;
     typedef DT::frag_t frag_t;
     constexpr int PTW = 15;
@@ -108,11 +116,12 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     constexpr int QW = TW + 3;                  // patch width 35, height TH + 3
     constexpr int QP = (TH + 3) * QW;           // 385 / 245 patch pixels
     constexpr int PLANE = NT * 16;              // one channel-half plane (8 channels x NT pixel slots)
-    constexpr int PATCH = 2 * PLANE;            // 16 / 8 KiB
+    constexpr int PATCH = (XPAIR ? 4 : 2) * PLANE;   // 16 / 8 KiB (XPAIR: hi planes, then lo planes)
+    constexpr int NPB = XPAIR ? 2 : 3;          // patch buffers
     constexpr int XROW = 16 * 256;              // one exchanged row: 16 pooled columns x 64 channels fp32
     constexpr int XBUF = 2 * NRP * XROW;        // slots 0..NRP-1: M[k] = max of conv rows 2k, 2k+1; NRP..2NRP-2: H[k], k = 1..NRP-1 (conv row 2k); 2NRP-1: KP
     static_assert(QP <= NT, "one DMA instruction per plane covers the patch");
-    constexpr int X_OFF = 3 * PATCH;
+    constexpr int X_OFF = NPB * PATCH;
     constexpr int BIAS_OFF = X_OFF + 2 * XBUF;
     constexpr int CORR_OFF = BIAS_OFF + 256;
 
@@ -126,6 +135,7 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
 
     const __amdgpu_buffer_rsrc_t rsrc_x = RAW ? __builtin_amdgcn_make_buffer_rsrc((void*)a.img, 0, a.img_bytes, 0x00020000)
                                               : __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_xl = __builtin_amdgcn_make_buffer_rsrc((void*)(XPAIR ? a.xl : a.x), 0, a.x_bytes, 0x00020000);
 
     // ---- the filter pair of this wave's channel tile, straight in MFMA operand layout (128 VGPRs, fetched once) ----------
     frag_t wfh[4][4], wfl[4][4];
@@ -140,7 +150,8 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     float* lbias = (float*)(smem + BIAS_OFF);
     float* lcorr = (float*)(smem + CORR_OFF);
     if (tid < 64) lbias[tid] = a.bias[tid];
-    for (int i = tid; i < 36 * 64; i += NT) lcorr[i] = a.corr[i];
+    if (!XPAIR)
+        for (int i = tid; i < 36 * 64; i += NT) lcorr[i] = a.corr[i];
 
     // ---- tile sequence of this workgroup: items blockIdx.x, + gridDim.x, ...; item = (segment, image, column strip) -------
     auto decode = [&](TileU8& d) {
@@ -180,6 +191,10 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         if (DIR_STEMU8_ABL & 4) return;
         dma16u(rsrc_x, dst + (wave * 64) * 16, v);
         dma16u(rsrc_x, dst + (NT + wave * 64) * 16, ok ? v + 16 : kOOBu);
+        if (XPAIR) {
+            dma16u(rsrc_xl, dst + (2 * NT + wave * 64) * 16, v);
+            dma16u(rsrc_xl, dst + (3 * NT + wave * 64) * 16, ok ? v + 16 : kOOBu);
+        }
     };
 
     // RAW: the 12 image bytes of this thread's patch pixel, as six zero-extended 16-bit loads (bytes 2k, 2k + 1 of row 0, then row 1)
@@ -239,7 +254,7 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         if (nxt.valid) load_raw(nxt);
     } else {
         issue_patch(cur, smem);
-        if (nxt.valid) issue_patch(nxt, smem + PATCH);
+        if (!XPAIR && nxt.valid) issue_patch(nxt, smem + PATCH);
     }
 
     // phase n: [wait patch n | barrier] issue patch n + 2 -> emit the pooled rows of tile n - 1 -> multiply tile n -> pool in
@@ -249,6 +264,8 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     for (;;) {
         if (RAW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (patch n was WRITTEN by this workgroup's own ds_writes in phase n - 1)
+        else if (XPAIR)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // patch n (issued one phase ago) landed; so did phase n - 1's stores
         else if (nxt.valid)
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // patch n landed; the 2 DMA ops of patch n + 1 may fly
         else
@@ -260,6 +277,8 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
             // last; then the fetch of patch n + 2 goes out, a whole phase ahead of its conversion
             if (nxt.valid) store_raw(smem + (pb == 2 ? 0 : pb + 1) * PATCH);
             if (pre.valid) load_raw(pre);
+        } else if (XPAIR) {      // two buffers: patch n + 1 into the one the MFMAs of phase n - 1 read last
+            if (nxt.valid) issue_patch(nxt, smem + (pb ^ 1) * PATCH);
         } else if (pre.valid) {  // buffer (n + 2) % 3 = (n - 1) % 3 was last read by the MFMAs of phase n - 1
             const int nb = pb == 0 ? 2 : pb - 1;
             issue_patch(pre, smem + nb * PATCH);
@@ -289,13 +308,17 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
                 }
                 // bias and ReLU commute with the max (both monotone): applied here, to the 8 pooled values of this thread, instead
                 // of to the 32 conv outputs of every lane
-                const f32x4_t bb0 = *(const f32x4_t*)(lbias + c8 * 8), bb1 = *(const f32x4_t*)(lbias + c8 * 8 + 4);
+                f32x4_t bb0 = {0.f, 0.f, 0.f, 0.f}, bb1 = {0.f, 0.f, 0.f, 0.f};
+                if (!XPAIR) {
+                    bb0 = *(const f32x4_t*)(lbias + c8 * 8);
+                    bb1 = *(const f32x4_t*)(lbias + c8 * 8 + 4);
+                }
                 u32x4_t oh, ol;
                 float mv[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    mv[e] = fmaxf(m0[e] + bb0[e], 0.f);
-                    mv[4 + e] = fmaxf(m1[e] + bb1[e], 0.f);
+                    mv[e] = fmaxf(XPAIR ? m0[e] : m0[e] + bb0[e], 0.f);
+                    mv[4 + e] = fmaxf(XPAIR ? m1[e] : m1[e] + bb1[e], 0.f);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -320,31 +343,49 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         // correction applies) or lies outside the conv map itself (masked out of the max): 13 % of the tiles at 1024^2
         const bool edge = cur.c <= 1 || 2 * (cur.c + TH - 1) + 4 > a.H || cur.pw0 == 0 || 2 * (2 * cur.pw0 + TW - 2) + 4 > a.W;
         f32x16_t acc[2];
+        if (XPAIR) {   // the generic pair form sums FROM the bias, like the kernels it replaces (same fp32 roundings)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t b4 = *(const f32x4_t*)(lbias + ci * 32 + 8 * g + 4 * lhi);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;   // (folds into the first MFMA's srcC = 0: no per-tile moves)
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = b4[e];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;   // (folds into the first MFMA's srcC = 0: no per-tile moves)
+        }
         // 20 fragments = patch rows 0..4 of this wave's row pair x 4 s2d columns: patch row q feeds conv row j = 0 through filter
         // row R = q and conv row j = 1 through R = q - 1, so the two rows share 12 of their 16 + 16 fragments.  Fragment of step
         // s + 1 requested before the MFMAs of step s; the pinned read : MFMA interleave keeps hipcc from hoisting every read
         // (80 VGPRs) above the chain.
         const char* xrow = pbuf + lhi * PLANE + ((rp * 2) * QW + lrow) * 16;
-        frag_t xf[2];
+        frag_t xf[2], xg[2];      // xg: the lo-plane fragments (XPAIR)
         xf[0] = *(const frag_t*)xrow;
+        if (XPAIR) xg[0] = *(const frag_t*)(xrow + 2 * PLANE);
 #pragma unroll
         for (int s = 0; s < 20; ++s) {
             const int q = s >> 2, ks = s & 3;
-            if (s + 1 < 20) xf[(s + 1) & 1] = *(const frag_t*)(xrow + (((s + 1) >> 2) * QW + ((s + 1) & 3)) * 16);
+            if (s + 1 < 20) {
+                xf[(s + 1) & 1] = *(const frag_t*)(xrow + (((s + 1) >> 2) * QW + ((s + 1) & 3)) * 16);
+                if (XPAIR) xg[(s + 1) & 1] = *(const frag_t*)(xrow + 2 * PLANE + (((s + 1) >> 2) * QW + ((s + 1) & 3)) * 16);
+            }
             if (!(DIR_STEMU8_ABL & 1)) {
                 if (q < 4) {
                     acc[0] = DT::mfma32(wfh[q][ks], xf[s & 1], acc[0]);
+                    if (XPAIR) acc[0] = DT::mfma32(wfh[q][ks], xg[s & 1], acc[0]);
                     acc[0] = DT::mfma32(wfl[q][ks], xf[s & 1], acc[0]);
                 }
                 if (q > 0) {
                     acc[1] = DT::mfma32(wfh[q - 1][ks], xf[s & 1], acc[1]);
+                    if (XPAIR) acc[1] = DT::mfma32(wfh[q - 1][ks], xg[s & 1], acc[1]);
                     acc[1] = DT::mfma32(wfl[q - 1][ks], xf[s & 1], acc[1]);
                 }
             }
+            if (XPAIR) continue;      // (the pinned interleave below is the two-product form's)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          // 1 DS read
             if (q > 0 && q < 4)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                      // 4 MFMAs (both conv rows)
@@ -356,14 +397,15 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         // along the row in registers: valid in the ODD lanes, window (l - 1, l, l + 1) ---------------------------------
         if (edge) {   // + the border-class correction of this conv pixel (the folded bias itself is added at the emit)
             const bool col_in = (unsigned)ox < (unsigned)a.OW;
-            const int cc = border_class(min(max(ox, 0), a.OW - 1), a.W);
+            const int cc = XPAIR ? 0 : border_class(min(max(ox, 0), a.OW - 1), a.W);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const bool in = col_in && (unsigned)(oy + j) < (unsigned)a.OH;
-                const int rc = border_class(min(max(oy + j, 0), a.OH - 1), a.H);
+                const int rc = XPAIR ? 0 : border_class(min(max(oy + j, 0), a.OH - 1), a.H);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4_t c4 = *(const f32x4_t*)(lcorr + (rc * 6 + cc) * 64 + ci * 32 + 8 * g + 4 * lhi);
+                    f32x4_t c4 = {0.f, 0.f, 0.f, 0.f};
+                    if (!XPAIR) c4 = *(const f32x4_t*)(lcorr + (rc * 6 + cc) * 64 + ci * 32 + 8 * g + 4 * lhi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float t = acc[j][4 * g + e];
@@ -416,7 +458,7 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         cur = nxt;
         nxt = pre;
         advance(pre);
-        pb = pb == 2 ? 0 : pb + 1;
+        pb = pb == NPB - 1 ? 0 : pb + 1;
         xb ^= 1;
     }
     ovf.flush(a.ovf);
@@ -529,6 +571,7 @@ int stem_pool_u8_launch(const void* img, const void* s2d, const void* w_hi, cons
     a.img = (const uint8_t*)img;
     a.img_bytes = raw ? (uint32_t)((size_t)B * H * W * 3) : 0;
     a.x = (const uint16_t*)s2d;
+    a.xl = nullptr;
     a.wh = (const uint16_t*)w_hi;
     a.wl = (const uint16_t*)w_lo;
     a.bias = bias;
@@ -583,6 +626,48 @@ int stem_pool_u8_launch(const void* img, const void* s2d, const void* w_hi, cons
         else
             hipLaunchKernelGGL((stem_pool_u8_kernel<2, false>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
     }
+    DIR_HIP_CHECK(hipGetLastError());
+    return DIR_OK;
+}
+
+// ---- the generic paired stem on this kernel (XPAIR): any fp32 image as an fp16 pair, nothing folded -------------------------
+// s2d_hi / s2d_lo: prep_input_pair's planes [B, H2, W2, 16]; w_hi / w_lo: the BatchNorm-folded filter pair [64][4][4][16]; bias:
+// bn1's folded bias.  Same sums, in the same order, as conv_pair.hip's stem_pool_pair_persist_kernel (bit-identical outputs).
+int stem_pool_pair_walk_launch(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
+                               void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream, int* ovf) {
+    if (!s2d_hi || !s2d_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo) return fail(DIR_ERR_INVALID, "stem_pool_pair: null pointer");
+    if ((size_t)B * H2 * W2 * 32 >= (1ull << 31)) return fail(DIR_ERR_INVALID, "stem_pool_pair: input exceeds 2^31 bytes; lower the batch");
+    StemU8Args a;
+    a.img = nullptr;
+    a.img_bytes = 0;
+    a.x = (const uint16_t*)s2d_hi;
+    a.xl = (const uint16_t*)s2d_lo;
+    a.wh = (const uint16_t*)w_hi;
+    a.wl = (const uint16_t*)w_lo;
+    a.bias = bias;
+    a.corr = nullptr;
+    a.yh = (uint16_t*)y_hi;
+    a.yl = (uint16_t*)y_lo;
+    a.B = B;
+    a.H = 2 * OH - 1;            // (only decides which tiles take the masked path: the smaller image of this conv size is the safe one)
+    a.W = 2 * OW - 1;
+    a.H2 = H2; a.W2 = W2; a.OH = OH; a.OW = OW;
+    a.PH = (OH - 1) / 2 + 1;
+    a.PW = (OW - 1) / 2 + 1;
+    a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
+    a.tiles_x = (a.PW + 14) / 15;
+    const int cus = cu_count(), slots = 2 * cus;
+    int T = 8;
+    while (T > 1 && (long)B * a.tiles_x * ((a.PH + 4 * T - 2) / (4 * T - 1)) < 2L * slots) T >>= 1;
+    a.seg_rows = 4 * T - 1;
+    a.nseg = (a.PH + a.seg_rows - 1) / a.seg_rows;
+    a.nitems = B * a.tiles_x * a.nseg;
+    a.ovf = ovf;
+    constexpr int LDS = 2 * 16384 + 2 * 4 * 4096 + 256 + 36 * 64 * 4;
+    static std::atomic<uint64_t> attr{0};
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)(stem_pool_u8_kernel<2, false, true>), LDS, attr));
+    const int grid = a.nitems < slots ? a.nitems : slots;
+    hipLaunchKernelGGL((stem_pool_u8_kernel<2, false, true>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;
 }

@@ -25,6 +25,10 @@ if os.environ.get('EXP_PICS'):
     img = torch.stack([pics[i % 8] for i in range(B)])
 else:
     img = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device='cuda', generator=g)
+if os.environ.get('EXP_F32'):      # the fp32 NCHW feed: prep_input_pair + the generic paired stem
+    sys.path.insert(0, ROOT)
+    import bench
+    img = bench.normalise_uint8(img.cpu()).cuda()
 for _ in range(3):
     net(img)
 torch.cuda.synchronize()

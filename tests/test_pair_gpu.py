@@ -240,7 +240,8 @@ def test_prep_input_pair(fmt):
     assert float((hi.float().cpu() - want).abs().max()) > 1e-4       # ... where one plane is 11 bits
 
 
-@pytest.mark.parametrize('B,H,W', [(2, 64, 96), (1, 75, 61), (1, 224, 224)], ids=['64x96', '75x61', '224'])
+@pytest.mark.parametrize('B,H,W', [(2, 64, 96), (1, 75, 61), (1, 224, 224), (3, 300, 130), (1, 513, 767), (1, 7, 9)],
+                         ids=['64x96', '75x61', '224', '300x130', '513x767', '7x9'])
 def test_stem_pool_pair_vs_torch_fp32(B, H, W):
     """conv 7x7 s2 + BN (folded) + ReLU + max-pool 3x3 s2 (resnet.py:115-119,158-161) on pairs against fp64 PyTorch
     of the same (hi + lo) operands; odd sizes exercise the image-border masks of both the conv and the pool."""
@@ -284,6 +285,16 @@ def test_stem_pool_pair_vs_torch_fp32(B, H, W):
         del os.environ['DIRTORCH_AMD_STEM_V1']
         _lib.reload_env()
     assert torch.equal(y1[0], y[0]) and torch.equal(y1[1], y[1])
+    # ... and so does round 5's persistent form (3 x 15 pooled tiles through an fp32 conv tile in LDS): the default since round 6 is
+    # stem_u8.hip's structure on pairs - tiles walking down column strips, the max-pool in registers - same sums, same order
+    os.environ['DIRTORCH_AMD_STEM_PAIR_OLD'] = '1'
+    _lib.reload_env()
+    try:
+        y2 = ops.stem_pool_pair(s2d, wp, bias.cuda(), (OH, OW))
+    finally:
+        del os.environ['DIRTORCH_AMD_STEM_PAIR_OLD']
+        _lib.reload_env()
+    assert torch.equal(y2[0], y[0]) and torch.equal(y2[1], y[1])
     # the fp16 stem of the same image differs from it at the fp16 level: the test can tell the two apart
     single = ops.stem_pool(s2d[0], wp[0], bias.cuda(), (OH, OW)).float().cpu().double()
     assert float((single - ref).abs().max()) > 1e-4
