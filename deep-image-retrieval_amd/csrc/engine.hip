@@ -731,24 +731,29 @@ int dir_engine::forward_pair_stem(const void* img, int B, int H, int W, int fmt,
         if (rc != DIR_OK) return rc;
         return prof_end(stream);
     }
-    if (img) {
+    const bool raw_f32 = img && fmt == DIR_IMG_F32_NCHW && stem_pool_pair_raw_ok(img, B, H, W);   // the stem splits the fp32 image itself
+    if (img && !raw_f32) {
         rc = prof_begin("prep_input", "prep_input_pair", 0, (double)B * H * W * 3 * (fmt == DIR_IMG_U8_NHWC ? 1 : 4) +
                         (double)B * p.H2 * p.W2 * 64, stream);
         if (rc != DIR_OK) return rc;
         rc = prep_input_pair(img, fmt, desc.mean, desc.std, s2d, s2d_lo, B, H, W, stream);
         if (rc != DIR_OK) return rc;
         if ((rc = prof_end(stream)) != DIR_OK) return rc;
-    } else {   // autotune: synthetic noise (the paired kernels themselves have nothing to tune)
+    } else if (!img) {   // autotune: synthetic noise (the paired kernels themselves have nothing to tune)
         const long n = (long)B * p.H2 * p.W2 * 16;
         hipLaunchKernelGGL(fill_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s2d, n, DIR_FP16);
         DIR_HIP_CHECK(hipGetLastError());
         DIR_HIP_CHECK(hipMemsetAsync(s2d_lo, 0, (size_t)n * 2, stream));
     }
     rc = prof_begin("conv1+maxpool", "stem_pool_pair", 2.0 * B * p.OH1 * p.OW1 * 64.0 * 147.0,
-                    4.0 * ((double)B * p.H2 * p.W2 * 16 + (double)B * p.PH * p.PW * 64 + 64 * 256), stream);
+                    (raw_f32 ? (double)B * H * W * 12 : 4.0 * (double)B * p.H2 * p.W2 * 16) + 4.0 * ((double)B * p.PH * p.PW * 64 + 64 * 256), stream);
     if (rc != DIR_OK) return rc;
-    rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, (uint16_t*)(base + p.bufA),
-                               (uint16_t*)(base + p.lo_stem), B, p.H2, p.W2, p.OH1, p.OW1, stream, d_ovf);
+    if (raw_f32)
+        rc = stem_pool_pair_walk_launch(nullptr, nullptr, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, (uint16_t*)(base + p.bufA),
+                                        (uint16_t*)(base + p.lo_stem), B, p.H2, p.W2, p.OH1, p.OW1, stream, d_ovf, img, H, W);
+    else
+        rc = stem_pool_pair_launch(s2d, s2d_lo, convs[0].d_w, convs[0].d_w_lo, convs[0].d_bias, (uint16_t*)(base + p.bufA),
+                                   (uint16_t*)(base + p.lo_stem), B, p.H2, p.W2, p.OH1, p.OW1, stream, d_ovf);
     if (rc != DIR_OK) return rc;
     return prof_end(stream);
 }

@@ -37,8 +37,10 @@ bool stem_pool_u8_raw_ok(const void* img, int B, int H, int W);
 int stem_pool_u8_launch(const void* img, const void* s2d, const void* w_hi, const void* w_lo, const float* bias, const float* corr,
                         void* y_hi, void* y_lo, int B, int H, int W, hipStream_t stream, int* ovf = nullptr, int seg_tiles = 0);
 // ... and the generic paired stem on the same kernel structure (stem_u8.hip XPAIR): what stem_pool_pair_launch runs by default
+bool stem_pool_pair_raw_ok(const void* img_f32, int B, int H, int W);
 int stem_pool_pair_walk_launch(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
-                               void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream, int* ovf = nullptr);
+                               void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream, int* ovf = nullptr,
+                               const void* img_f32 = nullptr, int H = 0, int W = 0);
 int rank_counts(const float* scores, int lds, int Q, int N, const int* probe_idx, int P, int* counts,
                 float* probe_scores, hipStream_t stream);
 int revisitop_ap(const int* probe_idx, int Q, int P, const int* counts, const float* pscores, const int* pos_off,

@@ -107,7 +107,8 @@ __device__ __forceinline__ int border_class(int o, int n) {
 // workgroups per CU).
 template <int NRP, bool RAW, bool XPAIR = false>
 __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kernel(const StemU8Args a) {
-    static_assert(!(RAW && XPAIR), "the raw-image form is the uint8 feed's");
+    // RAW && XPAIR: the patch pair comes straight from the fp32 NCHW image (a.img: six 8-byte loads per thread - the two horizontal
+    // neighbours of one channel and row -, split into (hi, lo) one tile later): prep_input_pair's arithmetic without its launch.
     typedef FP16 DT;
     typedef DT::frag_t frag_t;
     constexpr int PTW = 15;
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     constexpr int QP = (TH + 3) * QW;           // 385 / 245 patch pixels
     constexpr int PLANE = NT * 16;              // one channel-half plane (8 channels x NT pixel slots)
     constexpr int PATCH = (XPAIR ? 4 : 2) * PLANE;   // 16 / 8 KiB (XPAIR: hi planes, then lo planes)
-    constexpr int NPB = XPAIR ? 2 : 3;          // patch buffers
+    constexpr int NPB = XPAIR ? 2 : 3;          // patch buffers (16 KB each for pairs: two, so that two workgroups fit a CU)
     constexpr int XROW = 16 * 256;              // one exchanged row: 16 pooled columns x 64 channels fp32
     constexpr int XBUF = 2 * NRP * XROW;        // slots 0..NRP-1: M[k] = max of conv rows 2k, 2k+1; NRP..2NRP-2: H[k], k = 1..NRP-1 (conv row 2k); 2NRP-1: KP
     static_assert(QP <= NT, "one DMA instruction per plane covers the patch");
@@ -198,10 +199,25 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     };
 
     // RAW: the 12 image bytes of this thread's patch pixel, as six zero-extended 16-bit loads (bytes 2k, 2k + 1 of row 0, then row 1)
-    uint32_t rw[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t rw[XPAIR ? 12 : 6] = {};
     auto load_raw = [&](const TileU8& d) {
         const int iy = d.c - 2 + ppy, ix = 2 * d.pw0 - 3 + ppx;
         const bool ok = tid < QP && (unsigned)iy < (unsigned)a.H2 && (unsigned)ix < (unsigned)a.W2;
+        if (XPAIR) {   // fp32 NCHW: floats (c, 2 iy + dy, 2 ix) and (.., 2 ix + 1) as one 8-byte load; W even keeps them 8-byte aligned
+            const int plane = a.H * a.W;
+            const uint32_t o0 = ok ? (uint32_t)((((d.b * 3) * a.H + 2 * iy) * a.W + 2 * ix) * 4) : kOOBu;
+            const bool row1 = ok && 2 * iy + 1 < a.H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const uint32_t o = (dy == 0 ? ok : row1) ? o0 + (uint32_t)((c * plane + dy * a.W) * 4) : kOOBu;
+                    const u32x2_t v = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, o, 0, 0));
+                    rw[(c * 2 + dy) * 2] = v[0];
+                    rw[(c * 2 + dy) * 2 + 1] = v[1];
+                }
+            return;
+        }
         const uint32_t o0 = ok ? (uint32_t)(((d.b * a.H + 2 * iy) * a.W + 2 * ix) * 3) : kOOBu;      // offsets >= 2^31 read as 0
         const uint32_t o1 = (ok && 2 * iy + 1 < a.H) ? o0 + (uint32_t)(a.W * 3) : kOOBu;
 #pragma unroll
@@ -211,6 +227,36 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         }
     };
     auto store_raw = [&](char* dst) {   // channel (dy * 2 + dx) * 3 + c = byte 6 dy + 3 dx + c of the twelve; u / 256 is exact in fp16
+        if (XPAIR) {   // (hi, lo) = (fp16(v), fp16(v - hi)) per value, channels in s2d order, 12..15 zero: prep_input_pair's planes
+            float f[12];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) f[(dy * 2 + dx) * 3 + c] = __builtin_bit_cast(float, rw[(c * 2 + dy) * 2 + dx]);
+            u32x4_t h0, h1, l0, l1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t hh, ll;
+                split2u(f[2 * e], f[2 * e + 1], hh, ll);
+                h0[e] = hh;
+                l0[e] = ll;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                uint32_t hh, ll;
+                split2u(f[8 + 2 * e], f[9 + 2 * e], hh, ll);
+                h1[e] = hh;
+                l1[e] = ll;
+            }
+            h1[2] = h1[3] = l1[2] = l1[3] = 0;
+            *(u32x4_t*)(dst + tid * 16) = h0;
+            *(u32x4_t*)(dst + (NT + tid) * 16) = h1;
+            *(u32x4_t*)(dst + (2 * NT + tid) * 16) = l0;
+            *(u32x4_t*)(dst + (3 * NT + tid) * 16) = l1;
+            return;
+        }
         float f[12];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -264,7 +310,7 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
     for (;;) {
         if (RAW)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (patch n was WRITTEN by this workgroup's own ds_writes in phase n - 1)
-        else if (XPAIR)
+        else if (XPAIR)      // (the DMA form of the pair: RAW was taken above)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // patch n (issued one phase ago) landed; so did phase n - 1's stores
         else if (nxt.valid)
             asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // patch n landed; the 2 DMA ops of patch n + 1 may fly
@@ -273,9 +319,10 @@ __global__ void __launch_bounds__(128 * NRP, NRP == 2 ? 2 : 1) stem_pool_u8_kern
         ring_barrier();   // patch n visible; rows published in phase n - 1 visible; phase n - 1's LDS reads retired everywhere
 
         if (RAW) {
-            // the registers hold patch n + 1 (fetched in phase n - 1): into buffer (n + 1) % 3, which the MFMAs of phase n - 2 read
-            // last; then the fetch of patch n + 2 goes out, a whole phase ahead of its conversion
-            if (nxt.valid) store_raw(smem + (pb == 2 ? 0 : pb + 1) * PATCH);
+            // the registers hold patch n + 1 (fetched in phase n - 1): into buffer (n + 1) % NPB, which the MFMAs of phase n - 1 (or
+            // n - 2) read last - every wave left them before this barrier; then the fetch of patch n + 2 goes out, a whole phase
+            // ahead of its conversion
+            if (nxt.valid) store_raw(smem + (pb == NPB - 1 ? 0 : pb + 1) * PATCH);
             if (pre.valid) load_raw(pre);
         } else if (XPAIR) {      // two buffers: patch n + 1 into the one the MFMAs of phase n - 1 read last
             if (nxt.valid) issue_patch(nxt, smem + (pb ^ 1) * PATCH);
@@ -633,13 +680,22 @@ int stem_pool_u8_launch(const void* img, const void* s2d, const void* w_hi, cons
 // ---- the generic paired stem on this kernel (XPAIR): any fp32 image as an fp16 pair, nothing folded -------------------------
 // s2d_hi / s2d_lo: prep_input_pair's planes [B, H2, W2, 16]; w_hi / w_lo: the BatchNorm-folded filter pair [64][4][4][16]; bias:
 // bn1's folded bias.  Same sums, in the same order, as conv_pair.hip's stem_pool_pair_persist_kernel (bit-identical outputs).
+// img_f32 (optional): the fp32 NCHW image [B, 3, H, W] itself - with an even W (and 8-byte aligned, < 2^31 bytes) the kernel splits
+// it into the pair on its own and s2d_hi / s2d_lo are not read (stem_pool_pair_raw_ok); H, W: the image size (only used then).
+bool stem_pool_pair_raw_ok(const void* img_f32, int B, int H, int W) {
+    return img_f32 && (W % 2) == 0 && ((uintptr_t)img_f32 & 7) == 0 && (size_t)B * 3 * H * W * 4 < (1ull << 31) && !env().stem_u8_prep &&
+           !env().stem_pair_old && !env().stem_v1;
+}
+
 int stem_pool_pair_walk_launch(const void* s2d_hi, const void* s2d_lo, const void* w_hi, const void* w_lo, const float* bias,
-                               void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream, int* ovf) {
-    if (!s2d_hi || !s2d_lo || !w_hi || !w_lo || !bias || !y_hi || !y_lo) return fail(DIR_ERR_INVALID, "stem_pool_pair: null pointer");
-    if ((size_t)B * H2 * W2 * 32 >= (1ull << 31)) return fail(DIR_ERR_INVALID, "stem_pool_pair: input exceeds 2^31 bytes; lower the batch");
+                               void* y_hi, void* y_lo, int B, int H2, int W2, int OH, int OW, hipStream_t stream, int* ovf,
+                               const void* img_f32, int H, int W) {
+    const bool raw = stem_pool_pair_raw_ok(img_f32, B, H, W);
+    if ((!raw && (!s2d_hi || !s2d_lo)) || !w_hi || !w_lo || !bias || !y_hi || !y_lo) return fail(DIR_ERR_INVALID, "stem_pool_pair: null pointer");
+    if (!raw && (size_t)B * H2 * W2 * 32 >= (1ull << 31)) return fail(DIR_ERR_INVALID, "stem_pool_pair: input exceeds 2^31 bytes; lower the batch");
     StemU8Args a;
-    a.img = nullptr;
-    a.img_bytes = 0;
+    a.img = (const uint8_t*)(raw ? img_f32 : nullptr);
+    a.img_bytes = raw ? (uint32_t)((size_t)B * 3 * H * W * 4) : 0;
     a.x = (const uint16_t*)s2d_hi;
     a.xl = (const uint16_t*)s2d_lo;
     a.wh = (const uint16_t*)w_hi;
@@ -649,12 +705,12 @@ int stem_pool_pair_walk_launch(const void* s2d_hi, const void* s2d_lo, const voi
     a.yh = (uint16_t*)y_hi;
     a.yl = (uint16_t*)y_lo;
     a.B = B;
-    a.H = 2 * OH - 1;            // (only decides which tiles take the masked path: the smaller image of this conv size is the safe one)
-    a.W = 2 * OW - 1;
+    a.H = raw ? H : 2 * OH - 1;   // (the DMA form only uses them to decide which tiles take the masked path: the smaller image of this
+    a.W = raw ? W : 2 * OW - 1;   // conv size is the safe one; the raw form addresses the image with them)
     a.H2 = H2; a.W2 = W2; a.OH = OH; a.OW = OW;
     a.PH = (OH - 1) / 2 + 1;
     a.PW = (OW - 1) / 2 + 1;
-    a.x_bytes = (uint32_t)((size_t)B * H2 * W2 * 32);
+    a.x_bytes = raw ? 0 : (uint32_t)((size_t)B * H2 * W2 * 32);
     a.tiles_x = (a.PW + 14) / 15;
     const int cus = cu_count(), slots = 2 * cus;
     int T = 8;
@@ -665,9 +721,14 @@ int stem_pool_pair_walk_launch(const void* s2d_hi, const void* s2d_lo, const voi
     a.ovf = ovf;
     constexpr int LDS = 2 * 16384 + 2 * 4 * 4096 + 256 + 36 * 64 * 4;
     static std::atomic<uint64_t> attr{0};
+    static std::atomic<uint64_t> attr_raw{0};
     DIR_HIP_CHECK(ensure_dynamic_lds((const void*)(stem_pool_u8_kernel<2, false, true>), LDS, attr));
+    DIR_HIP_CHECK(ensure_dynamic_lds((const void*)(stem_pool_u8_kernel<2, true, true>), LDS, attr_raw));
     const int grid = a.nitems < slots ? a.nitems : slots;
-    hipLaunchKernelGGL((stem_pool_u8_kernel<2, false, true>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
+    if (raw)
+        hipLaunchKernelGGL((stem_pool_u8_kernel<2, true, true>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
+    else
+        hipLaunchKernelGGL((stem_pool_u8_kernel<2, false, true>), dim3((unsigned)grid), dim3(256), LDS, stream, a);
     DIR_HIP_CHECK(hipGetLastError());
     return DIR_OK;
 }

@@ -233,7 +233,7 @@ def test_timed_configuration_vs_oracle(B, dtype):
 # (round-5 review, "What's weak" 1a: the kernels the bench number is made of - the paired stem, conv_pair's conv1 of block 0, the
 # paired-weight seams of layer1, in-place identity blocks in layers 3-4 - met the oracle only inside bench.py's own parity leg)
 FP16P_HEAD = {
-    'f32': {'prep_input': 'prep_input_pair', 'conv1+maxpool': 'stem_pool_pair'},
+    'f32': {'conv1+maxpool': 'stem_pool_pair'},     # (round 6: no prep launch either - the paired stem splits the fp32 image itself)
     'u8': {'conv1+maxpool': 'stem_pool_u8'},        # (no prep launch: at an even width the stem converts the image bytes itself)
 }
 FP16P_MIX = {'layer1.0.conv1': 'conv_pair<128x64_xw>', 'layer1.0.ds+c3c1': 'conv_c3c1<64,ds,wp>',
@@ -274,7 +274,7 @@ def test_timed_configuration_fp16p_vs_oracle_on_the_calibrated_checkpoint(feed):
         assert used.get(layer) == kern, (layer, used.get(layer))
     for s_ in (2, 3, 4):
         assert used.get('layer%d.0.ds+conv3' % s_, '').endswith('/dual>'), used
-    assert feed != 'u8' or 'prep_input' not in used, used
+    assert 'prep_input' not in used, used
     assert np.isfinite(got).all() and not net.overflowed()
     ref = cached(('timed-calib-desc', feed), lambda: oracle_desc(sd, arch, xo, chunk=1))
     err = 1 - O.cosine(got[rows], ref)

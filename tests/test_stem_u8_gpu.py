@@ -153,3 +153,32 @@ def test_engine_uint8_feed_fp16p_vs_fp32_feed_and_oracle(arch, B, H, W):
         _lib.reload_env()
     assert used2.get('conv1+maxpool') == 'stem_pool_pair', used2
     assert np.all(1 - O.cosine(a, c) < 5e-5)
+
+
+@pytest.mark.parametrize('H,W', [(96, 128), (97, 130), (75, 61)], ids=['96x128', '97x130', '75x61_odd_w'])
+def test_fp32_feed_stem_reads_the_image_itself(H, W, monkeypatch):
+    """The generic paired stem on the fp32 NCHW feed (net(x) on the reference's normalised tensor, rmac_resnet.py:39): with an even
+    width the kernel splits the image into its (hi, lo) planes on its own - no prep_input_pair launch - and the descriptors equal the
+    two-kernel form's bit for bit (DIRTORCH_AMD_STEM_U8_PREP=1), which an odd width still takes."""
+    import dir_oracle as O
+    from dirtorch_amd import nets
+    sd = O.synth_state_dict('resnet50', seed=7)
+    x = O.synth_images(5, 3, H, W).cuda()
+
+    def run():
+        net = nets.create_model('resnet50_rmac', pretrained='')
+        net.load_state_dict(sd)
+        net.compute_dtype = 'fp16p'
+        net.cuda().eval()
+        net.set_profiling(True)
+        d = net(x).clone()
+        return d, {r['name']: r['kernel'] for r in net.get_profile()}
+    d_raw, used = run()
+    assert used.get('conv1+maxpool') == 'stem_pool_pair'
+    assert ('prep_input' in used) == (W % 2 == 1), used
+    monkeypatch.setenv('DIRTORCH_AMD_STEM_U8_PREP', '1')
+    d_prep, used2 = run()
+    assert used2.get('prep_input') == 'prep_input_pair'
+    assert torch.equal(d_raw, d_prep)
+    ref = O.rmac_forward(sd, 'resnet50', x.cpu()).numpy()
+    assert np.all(1 - O.cosine(d_raw.cpu().numpy(), ref) < 1e-5)
