@@ -69,6 +69,7 @@ struct ConvVariant {
                                // 6 = LDS-patch 3x3, 512 pixels x 128 channels, double-buffered 32-channel planes (conv_patchw.hip)
                                // 7 = persistent 128x256 1x1 without a residual, one K ring over all tiles of a workgroup (conv_ring.hip)
                                // 8 = 64 -> 64 channel 3x3 with the filter resident in LDS, loader / consumer waves (conv_patchlc.hip)
+                               // 9 = two-source 1x1 (launch_dual only) with register-stationary weights (conv_wregd.hip)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
     ConvLaunchFn launch_dual[2]; // two-source K instantiation (ConvArgs::x2: conv3 + downsample in one GEMM), or nullptr
 };
@@ -82,6 +83,9 @@ hipError_t conv_patch64_lc_launch(const ConvArgs& a, int dtype, hipStream_t stre
 bool conv1x1_ring_admissible(const ConvArgs& a);
 hipError_t conv1x1_ring_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_wreg_admissible(const ConvArgs& a);
+bool conv1x1_wregd_admissible(const ConvArgs& a);   // two-source form, K = 128 + 256 (layer2's first block)
+hipError_t conv1x1_wregd_bf16(const ConvArgs& a, hipStream_t stream);
+hipError_t conv1x1_wregd_fp16(const ConvArgs& a, hipStream_t stream);
 hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 // the layer3 seam (planes 256): weights streamed from L2 through an LDS ring by loader waves (conv_seam3.hip); reached
 // through conv_c3c1_admissible / conv_c3c1_launch like the register-stationary forms

@@ -489,6 +489,10 @@ static const ConvVariant kVariants[] = {
 #endif
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
     {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}, {nullptr, nullptr}},
+    // the two-source GEMM of layer2's first block (K = 128 + 256) with 32 output channels x 384 inputs per wave held in VGPRs,
+    // 256 channels per workgroup (conv_wregd.hip); a launch_dual-only entry
+    {"64x256_wregd1x1", 64, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 9, {nullptr, nullptr},
+     {conv1x1_wregd_bf16, conv1x1_wregd_fp16}},
 };
 static constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -508,6 +512,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
 #endif
     if (cv.kind == 8) return conv_patch64_lc_admissible(a);
+    if (cv.kind == 9) return conv1x1_wregd_admissible(a);   // (two-source shapes only: never true for a plain conv)
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
     return true;
@@ -623,6 +628,14 @@ int conv_pick_dual_variant(const ConvArgs& a, bool any_size) {
                     a.Cin % 64 == 0 && a.Cin2 % 64 == 0 && a.res == nullptr && a.ksplit <= 1;
     if (!ok) return -1;
     // (any_size: the op-level entry point runs the form on small shapes too - the tests')
+    // layer2's first block (K = 128 + 256): weights stationary in registers, from ~4 pixel tiles per persistent workgroup
+    // (round 6, A/B at batch 32 in profiles/r06_wregd.txt; DIRTORCH_AMD_NO_WREGD: the DUAL ring again)
+    {
+        const int v = find_variant("64x256_wregd1x1");
+        if (v >= 0 && !env().no_wregd && conv1x1_wregd_admissible(a) &&
+            (any_size || (long)ceil_div(a.M, 64) * (a.Cout / 256) >= 1024))
+            return v;
+    }
     if (a.Cout % 256 != 0 || (!any_size && (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192)) return -1;
     const int v = find_variant("256x256_persist1x1_x3");
     if (v < 0 || kVariants[v].launch_dual[0] == nullptr) return -1;
@@ -711,7 +724,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (a.x2) {   // two-source K: conv3 + downsample in one GEMM
         if (variant < 0) variant = conv_pick_dual_variant(a);
         if (variant < 0 || variant >= kNumVariants || kVariants[variant].launch_dual[0] == nullptr ||
-            a.Cout % kVariants[variant].BN != 0 || a.R != 1 || a.S != 1 || a.stride != 1 || a.res || a.ksplit > 1 ||
+            a.Cout % kVariants[variant].BN != 0 || (kVariants[variant].kind == 9 && !conv1x1_wregd_admissible(a)) || a.R != 1 || a.S != 1 || a.stride != 1 || a.res || a.ksplit > 1 ||
             a.Cin2 % 64 != 0 || a.Ktot != a.Cin + a.Cin2 || ((uintptr_t)a.x2 & 15) ||
             (long)a.B * a.H2 * a.W2 * a.Cin2 >= (1L << 30))
             return fail(DIR_ERR_INVALID, "conv: no two-source form for this shape / variant");

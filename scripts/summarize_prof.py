@@ -93,6 +93,9 @@ def short(name):
     m = re.search(r'conv1x1_wreg_kernel<dir::(\w+), (\d+)>', name)
     if m:
         return 'conv_igemm<64x512_wreg1x1>[%s]' % m.group(1).lower()
+    m = re.search(r'conv1x1_wregd_kernel<dir::(\w+), (\d+), (\d+)>', name)
+    if m:   # the two-source register-stationary GEMM of layer2's first block (csrc/conv_wregd.hip)
+        return 'conv_igemm<64x256_wregd1x1/dual>[%s]' % m.group(1).lower()
     m = re.search(r'stem_pool_u8_kernel<(\d+), (\w+)(?:, (\w+))?>', name)
     if m:   # <NRP, RAW[, XPAIR]> (csrc/stem_u8.hip): XPAIR = the generic paired stem on the walking kernel
         return 'stem_pool_pair_kernel' if m.group(3) == 'true' else 'stem_pool_u8_kernel'

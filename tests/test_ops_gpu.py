@@ -40,6 +40,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
     LDS-patch variants are 3x3 stride-1 pad-1 with Cin == Cout == BN; the register-stationary-weights
     kernel is for the residual 1x1 convs with K <= 256 and Cout a multiple of 512."""
     bn = int(name.split('_')[0].split('x')[1])
+    if 'wregd1x1' in name:               # a two-source-only table entry (conv_wregd.hip): never a plain conv's kernel
+        return False
     if 'wreg1x1' in name:
         return k == 1 and stride == 1 and pad == 0 and Cout % 512 == 0 and Cin in (128, 256) and has_res
     if 'patchlc3x3' in name:             # filter resident in LDS, loader / consumer waves: 64 -> 64 without a residual
@@ -728,7 +730,7 @@ DUAL_SHAPES = [(2, 13, 11, 128, 512, 256, 2), (1, 9, 17, 256, 1024, 512, 2), (1,
 @pytest.mark.parametrize('dname', ['bf16', 'fp16'])
 @pytest.mark.parametrize('B,OH,OW,Cin,Cout,Cin2,s2', DUAL_SHAPES + [(2, 64, 64, 128, 512, 256, 2), (3, 33, 47, 256, 1024, 512, 2),
                                                       (4, 96, 128, 128, 512, 256, 2)])
-def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2, s2, dname):
+def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2, s2, dname, monkeypatch):
     """dir_conv_dual: relu(conv1x1(t2; w3) + b3 + conv1x1_stride(x; wds) + bds) as one GEMM whose K runs over
     two tensors, against the fp32 CPU oracle of the two convolutions on the same rounded operands (odd input
     sizes: the strided pixel map, ragged last tile).  The kernel: the persistent deep-X ring with a second pixel source
@@ -751,6 +753,38 @@ def test_conv3_plus_downsample_as_one_two_source_gemm(B, OH, OW, Cin, Cout, Cin2
     ref = F.relu(conv_reference(t2, w3, b3, None, 1, 0, False) + ds)
     check_close(y, ref, dname, 'two-source conv3 + downsample')
     assert torch.equal(y, ops.conv_dual(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), stride2=s2, relu=True))
+    if (Cin, Cin2) == (128, 256):
+        # layer2's shape runs on conv_wregd.hip (round 6: weights stationary in registers, 64-pixel tiles, ragged last tile,
+        # several tiles per workgroup at the last shape); the DUAL ring it replaces forms the same sums bit for bit
+        monkeypatch.setenv('DIRTORCH_AMD_NO_WREGD', '1')
+        y_ring = ops.conv_dual(t2.cuda(), x.cuda(), wcat.cuda(), (b3 + bds).cuda(), stride2=s2, relu=True)
+        monkeypatch.delenv('DIRTORCH_AMD_NO_WREGD')
+        assert torch.equal(y, y_ring)
+
+
+def test_two_source_register_stationary_kernel_at_scale(monkeypatch):
+    """conv_wregd.hip at layer2.0's size for batch 8 (1024 pixel tiles per channel slice: every persistent workgroup walks 8
+    tiles through both input buffers) and with a ragged last tile, against the DUAL ring kernel (bit for bit) and - on a
+    sample of pixels - against fp64 of the same rounded operands."""
+    ops = _ops()
+    for dname, (B, OH, OW) in (('fp16', (8, 128, 128)), ('bf16', (5, 77, 93))):
+        dt = DTYPES[dname]
+        g = torch.Generator(device='cuda').manual_seed(5)
+        t2 = torch.relu(torch.randn(B, OH, OW, 128, device='cuda', generator=g)).to(dt)
+        x = torch.relu(torch.randn(B, 2 * OH, 2 * OW - 1, 256, device='cuda', generator=g)).to(dt)
+        wcat = (torch.randn(512, 384, device='cuda', generator=g) * 0.07).to(dt)
+        bias = torch.randn(512, device='cuda', generator=g) * 0.2
+        y = ops.conv_dual(t2, x, wcat, bias, stride2=2, relu=True)
+        monkeypatch.setenv('DIRTORCH_AMD_NO_WREGD', '1')
+        y_ring = ops.conv_dual(t2, x, wcat, bias, stride2=2, relu=True)
+        monkeypatch.delenv('DIRTORCH_AMD_NO_WREGD')
+        assert torch.equal(y, y_ring), dname
+        idx = torch.randint(0, B * OH * OW, (4096,), device='cuda', generator=g)
+        xs = x[:, ::2, ::2][:, :OH, :OW].reshape(-1, 256)[idx].double()
+        ref = torch.relu(torch.cat([t2.reshape(-1, 128)[idx].double(), xs], 1) @ wcat.double().t() + bias.double())
+        got = y.reshape(-1, 512)[idx].double()
+        tol = 2.0 ** (-8 if dname == 'bf16' else -11)
+        assert ((got - ref).abs() <= tol * ref.abs() + 1e-2).all(), dname
 
 
 def test_fused_seam_argument_errors():
