@@ -55,7 +55,7 @@ __device__ inline uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shr) {
 // workgroup - lives on the persistent ring since round 4: conv_persist.hip DUAL, bit-identical, 5-13 % faster.)
 template <class DT, int BM, int BN, int WGM, int WGN, int NST, int BK, bool CIN16, bool SPLITK>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvArgs a) {
-    static_assert(NST >= 2 && NST <= 4, "ring depth");
+    static_assert(NST >= 2 && NST <= 8, "ring depth");
     static_assert((BK == 64 || BK == 32) && (!CIN16 || BK == 64), "K-step");
     constexpr int RB = BK * 2;    // bytes per LDS row (one pixel / one output channel, BK channels)
     constexpr int CPR = BK / 8;   // 16-byte chunks per row
@@ -290,7 +290,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm_kernel(const ConvAr
     if (slot_i == NST) slot_i = 0;
     for (int t = 0; t < T; ++t) {
         const int ahead = issued - 1 - t;  // stages issued beyond t: 0 .. NST-2
-        if (NST >= 4 && ahead >= 2) {
+        // (deep rings, round 6: the small-tile variants of the small-map regime keep up to six stages in flight)
+        static_assert((NST - 2) * LPS <= 63, "vmcnt immediate");
+        if (NST >= 8 && ahead >= 6) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST >= 8 ? 6 * LPS : 0) : "memory");
+        } else if (NST >= 7 && ahead >= 5) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST >= 7 ? 5 * LPS : 0) : "memory");
+        } else if (NST >= 6 && ahead >= 4) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST >= 6 ? 4 * LPS : 0) : "memory");
+        } else if (NST >= 5 && ahead >= 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST >= 5 ? 3 * LPS : 0) : "memory");
+        } else if (NST >= 4 && ahead >= 2) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPS) : "memory");
         } else if (NST >= 3 && ahead == 1) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LPS) : "memory");
@@ -466,6 +476,12 @@ static const ConvVariant kVariants[] = {
     // 16 waves of 64x64 on one CU (128 VGPRs): more fragment reads in flight under the matrix
     // pipe - the 3x3 convs of layer3/4
     DIR_VARIANT(256, 256, 4, 4, 2, 64, "256x256_w4x4"),
+    // the small-map regime (batch 1 / 224^2 buckets: 1 000 - 13 000 pixels per layer): 64x64 tiles give every CU one even at
+    // 4 096 pixels x 256 channels, and an 8-slot ring (six 16 KB stages in flight) covers the L2 round trip that a 2- or 4-slot
+    // ring of such short stages exposes on every K-step
+    DIR_VARIANT_SK(64, 64, 2, 2, 8, 64, "64x64_w2x2_s8"),
+    DIR_VARIANT_SK(64, 128, 2, 2, 6, 64, "64x128_w2x2_s6"),
+    DIR_VARIANT_SK(128, 64, 2, 2, 6, 64, "128x64_w2x2_s6"),
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},

@@ -83,7 +83,11 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
             const int m = tile_m * BM + i * 64 + (tid >> 3);
             uint32_t off;
             if (a.flat) {
+#ifdef DIR_PERSIST_BLOCKED   // experiment builds only (timing): X read as [M / 256][Cin / 64][256 px][64 ch] - every K-stage one contiguous 32 KB
+                off = (uint32_t)(tile_m * (BM * a.Cin * 2) + (i * 64 + (tid >> 3)) * 128 + srcchunk * 16);
+#else
                 off = (uint32_t)((m * a.Cin + srcchunk * 8) * 2);
+#endif
             } else {  // strided 1x1 (downsample): output pixel -> input pixel
                 const uint32_t mm = m < a.M ? (uint32_t)m : 0u;
                 const uint32_t b = fast_div_q(mm, a.div_ohw_mul, a.div_ohw_shr);
@@ -117,7 +121,11 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
             return;
         }
 #pragma unroll
+#ifdef DIR_PERSIST_BLOCKED
+        for (int i = 0; i < NA; ++i) dma16q(rsrc_x, dst + (i * NT + wave * 64) * 16, xvoff[i], a.flat ? t * (BM * 128) : t * 128);
+#else
         for (int i = 0; i < NA; ++i) dma16q(rsrc_x, dst + (i * NT + wave * 64) * 16, xvoff[i], t * 128);
+#endif
     };
     auto issue_w = [&](int t, char* dst) {
 #pragma unroll

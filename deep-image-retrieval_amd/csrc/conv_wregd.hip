@@ -18,13 +18,13 @@
 #include "dir_common.h"
 #include "conv_igemm.h"
 
+#ifndef DIR_WREGD_ABL   // experiment builds only (scripts/exp_abl.sh conv_wregd DIR_WREGD_ABL <bits>): 1 no MFMAs, 2 no stores,
+#define DIR_WREGD_ABL 0 // 4 the second source read as a flat tensor (no stride), 8 no pixel loads - timing only
+#endif
+
 namespace dir {
 
 static constexpr uint32_t kOOBd = 0x80000000u;
-
-__device__ __forceinline__ uint32_t fast_div_d(uint32_t n, uint32_t mul, uint32_t shr) {
-    return mul ? (__umulhi(n, mul) >> shr) : n;
-}
 
 // KB1 / KB2 = 64-channel blocks of the first (flat) / second (strided) source
 template <class DT, int KB1, int KB2>
@@ -35,8 +35,10 @@ __global__ void __launch_bounds__(512) conv1x1_wregd_kernel(const ConvArgs a) {
     constexpr int KB = KB1 + KB2;
     constexpr int KS = KB * 4;                 // 16-wide k-slices
     constexpr int XBUF = KB * BM * 128;        // one input tile: KB blocks of [64 px][128 B]
-    constexpr int SROW = BNG * 2 + 16;         // staging row: 256 packed channels + pad (bank spread, 16-byte aligned)
+    constexpr int SROW = BNG * 2;              // staging row: 256 packed channels (16-byte chunks XOR-swizzled by the pixel row)
+    constexpr int SBUF = BM * SROW;            // the staged output tile (32 KB)
     constexpr int STG_OFF = 2 * XBUF;          // staging above the two input buffers
+    constexpr int BIAS_OFF = STG_OFF + SBUF;   // the workgroup's 256 bias values (accumulators start there: read per tile)
     typedef typename DT::frag_t frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,15 +72,13 @@ __global__ void __launch_bounds__(512) conv1x1_wregd_kernel(const ConvArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         wf[ks] = *(const DIR_GLOBAL frag_t*)(a.w + (size_t)(n_wave + lrow) * a.Ktot + ks * 16 + 8 * lhi);
-    // bias of the 16 channels a lane accumulates: rows 8 g + 4 lhi + e of the wave's channel tile
-    f32x4_t bz[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bz[g] = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_wave + 8 * g + 4 * lhi);
     // "already in registers" (conv_wreg.hip: keeps the wait for these loads out of the loop)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bz[g]));
+    // the workgroup's bias values live in LDS: the accumulators of every tile start at the 16 channels of their lane
+    // (rows 8 g + 4 lhi + e of the wave's channel tile) - four 16-byte reads per tile instead of 16 registers
+    if (tid < BNG) ((float*)(smem + BIAS_OFF))[tid] = a.bias[sl * BNG + tid];
+    const char* const bzl = smem + BIAS_OFF + (wave * BNW + 4 * lhi) * 4;
 
     // ---- per-lane constants ------------------------------------------------------------------------------------
     // input tile image in LDS: block kb (64 channels), pixel row p, 16-byte chunk c at
@@ -90,20 +90,25 @@ __global__ void __launch_bounds__(512) conv1x1_wregd_kernel(const ConvArgs a) {
     const int lbase = lrow * 128;
 
     // input tile t -> KB registers per lane (out-of-range rows read zeros)
+    // (branch-free on purpose: with exec-masked regions in the loop the compiler's vmcnt bookkeeping fell back to a wait for
+    // the previous step's requests at the top of every other step - the admissibility rule keeps OW > 1, so the divisions
+    // need no special case)
     auto load_x = [&](int t, u32x4_t* xr) {
         const int m = t * BM + spix;
         const bool in = m < a.M;
-        const uint32_t base = in ? (uint32_t)((m * a.Cin + sslot * 8) * 2) : kOOBd;
+        const uint32_t mm = in ? (uint32_t)m : 0u;
+        const uint32_t off1 = (mm * (uint32_t)a.Cin + sslot * 8) * 2;
+        const uint32_t base = in ? off1 : kOOBd;
 #pragma unroll
         for (int i = 0; i < KB1; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base, i * 128, 0);
         // output pixel -> pixel (oh * stride2, ow * stride2) of the second source
-        const uint32_t mm = in ? (uint32_t)m : 0u;
-        const uint32_t b = fast_div_d(mm, a.div_ohw_mul, a.div_ohw_shr);
+        const uint32_t b = __umulhi(mm, a.div_ohw_mul) >> a.div_ohw_shr;
         const uint32_t rem = mm - b * (uint32_t)(a.OH * a.OW);
-        const uint32_t oh = fast_div_d(rem, a.div_ow_mul, a.div_ow_shr);
+        const uint32_t oh = __umulhi(rem, a.div_ow_mul) >> a.div_ow_shr;
         const uint32_t ow = rem - oh * (uint32_t)a.OW;
-        const uint32_t base2 =
-            in ? (uint32_t)((((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.Cin2 + sslot * 8) * 2) : kOOBd;
+        const uint32_t off2 = (((b * a.H2 + oh * a.stride2) * a.W2 + ow * a.stride2) * a.Cin2 + sslot * 8) * 2;
+        const uint32_t base2 = (DIR_WREGD_ABL & 4) ? (in ? (mm * (uint32_t)a.Cin2 + sslot * 8) * 2 : kOOBd) : (in ? off2 : kOOBd);
+        if (DIR_WREGD_ABL & 8) return;
 #pragma unroll
         for (int i = 0; i < KB2; ++i) xr[KB1 + i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2, base2, i * 128, 0);
     };
@@ -113,85 +118,107 @@ __global__ void __launch_bounds__(512) conv1x1_wregd_kernel(const ConvArgs a) {
     };
 
     char* const stg = smem + STG_OFF;
-    // this lane's staging writes: pixel j * 32 + lrow, channels wave * 32 + 8 g + 4 lhi .. + 3 (8 bytes)
-    char* const swr = stg + lrow * SROW + (wave * BNW + 4 * lhi) * 2;
-    // ... and its share of the tile's stores: 16-byte chunk q = tid + 512 k -> pixel q / 32, chunk q % 32
+    // this lane's staging writes: pixel j * 32 + lrow, channels wave * 32 + 8 g + 4 lhi .. + 3 (8 bytes) = half of the 16-byte
+    // chunk wave * 4 + g, stored at chunk position (wave * 4 + g) ^ lrow of the pixel's row: conflict-free for the 8-byte
+    // writes (16 pixel rows per LDS pass) and for the 16-byte reads below (32 chunks of one row per pass)
+    const int swr = lrow * SROW + (((wave * 4) ^ lrow) << 4) + lhi * 8;   // chunk g: swr ^ (g << 4)
+    // ... and its share of a tile's stores: 16-byte chunk q = tid + 512 k -> pixel k * 16 + tid / 32, chunk tid % 32
     const int cpix = tid >> 5, cchunk = tid & 31;
-    const char* const srd = stg + cpix * SROW + cchunk * 16;
     const uint32_t ycol = (uint32_t)((sl * BNG) * 2 + cchunk * 16);
 
-    u32x4_t xr[KB];
-    load_x(tile, xr);
-    int cur = 0;
-    store_x(xr, smem);
-    ring_barrier();   // first tile staged
-    for (;;) {
-        const bool more = tile + per < mt;
-        const int next = more ? tile + per : tile;   // last step: a harmless repeat
-        load_x(next, xr);                            // lands during this tile's MFMAs and stores
-        const int m0 = tile * BM;
-
+    // One step = one 64-pixel tile.  While the MFMAs of tile i run, the same instruction stream carries the memory work
+    // of its neighbours: the global stores of tile i - 1 (read back from the staging tile it was packed into at the end
+    // of the last step) and the LDS publication of tile i + 1 (requested one step ago); tile i + 2 is requested at the top.
+    // Two tiles of the pixel operand are in flight in REGISTERS (2 x KB x 16 bytes per lane: ~96 KB per CU).
+    // First form of this kernel: pack / barrier / stores / publish / barrier after the MFMAs, in lock-step - compute alone
+    // 169 us, memory alone 183 us, together 270 us (profiles/r06_wregd.txt).
+    // The loop is a COUNTED pair of steps without a break: an early exit between the halves gave the structurised loop a
+    // static path from the middle of a step to its header, and with it a wait for the newest requests at the top of every
+    // step.  A workgroup with an odd number of tiles therefore computes and stores its last tile twice (same values).
+    const int tile0 = tile;
+    const int n = (mt - tile0 + per - 1) / per;   // pixel tiles of this workgroup (>= 1)
+    auto tile_at = [&](int i) { return tile0 + (i < n ? i : n - 1) * per; };
+    const float floor_v = a.relu ? 0.f : -__builtin_huge_valf();
+    // stores of pixel rows k * 16 + cpix of the staged tile (rows from m0 on; m0 = M: nothing to store yet)
+    auto store_rows = [&](int m0, int k) {
+        const int pix = k * 16 + cpix;
+        const u32x4_t ov = *(const u32x4_t*)(stg + pix * SROW + ((cchunk ^ (pix & 31)) << 4));
+        const int m = m0 + pix;
+        const uint32_t off = m < a.M ? (uint32_t)m * (uint32_t)(a.Cout * 2) + ycol : kOOBd;
+        if (!(DIR_WREGD_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, off, 0, 0);
+    };
+    auto step = [&](int i, const int cur, u32x4_t* pub, u32x4_t* ld) {
+        load_x(tile_at(i + 2), ld);
+        const int m_prev = i > 0 ? tile_at(i - 1) * BM : a.M;
         const char* xb = smem + cur * XBUF;
+        char* const xpub = smem + (cur ^ 1) * XBUF;
         f32x16_t acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t b4 = *(const f32x4_t*)(bzl + g * 32);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = bz[g][e];
+                for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = b4[e];
+            }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const char* p = xb + (ks >> 2) * (BM * 128) + lbase + (((2 * (ks & 3) + lhi) ^ lswz) << 4);
-            const frag_t x0 = *(const frag_t*)p;
-            const frag_t x1 = *(const frag_t*)(p + 32 * 128);
-            acc[0] = DT::mfma32(wf[ks], x0, acc[0]);
-            acc[1] = DT::mfma32(wf[ks], x1, acc[1]);
-            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int k4 = 0; k4 < ((DIR_WREGD_ABL & 1) ? 0 : 4); ++k4) {
+                const int ks = kb * 4 + k4;
+                const char* p = xb + kb * (BM * 128) + lbase + (((2 * k4 + lhi) ^ lswz) << 4);
+                const frag_t x0 = *(const frag_t*)p;
+                const frag_t x1 = *(const frag_t*)(p + 32 * 128);
+                acc[0] = DT::mfma32(wf[ks], x0, acc[0]);
+                acc[1] = DT::mfma32(wf[ks], x1, acc[1]);
+            }
+            // the neighbours' memory work, one piece per 64-channel block of the K loop
+            if (kb < 4) store_rows(m_prev, kb);
+            *(u32x4_t*)(xpub + kb * (BM * 128) + sdst) = pub[kb];
+            __builtin_amdgcn_sched_barrier(0);
         }
+        ring_barrier();   // every wave has read the staged tile i - 1 (and is done with input buffer `cur`)
         // ---- ReLU, pack, stage: a lane holds 16 channels of pixel j * 32 + lrow ---------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v[4] = {acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_v);   // (ReLU as a max with 0 or -inf: no branch per store)
                 u32x2_t ov;
                 ov[0] = DT::pack(v[0], v[1]);
                 ov[1] = DT::pack(v[2], v[3]);
                 ovf.see(ov);
-                *(u32x2_t*)(swr + j * (32 * SROW) + g * 16) = ov;
+                *(u32x2_t*)(stg + j * (32 * SROW) + (swr ^ (g << 4))) = ov;
             }
-        ring_barrier();   // the staged tile is complete (and every wave is done with input buffer `cur`)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u32x4_t ov = *(const u32x4_t*)(srd + k * (16 * SROW));
-            const int m = m0 + k * 16 + cpix;
-            const uint32_t off = m < a.M ? (uint32_t)m * (uint32_t)(a.Cout * 2) + ycol : kOOBd;
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, off, 0, 0);
-        }
-        if (!more) break;
-        // publish the next tile into the buffer last read one step ago; the barrier also closes this step's
-        // staging reads before the next step's staging writes
-        store_x(xr, smem + (cur ^ 1) * XBUF);
-        tile = next;
-        cur ^= 1;
-        ring_barrier();
+        ring_barrier();   // tile i is staged, tile i + 1 published
+    };
+    u32x4_t xa[KB] = {}, xq[KB] = {};
+    load_x(tile_at(0), xa);
+    store_x(xa, smem);
+    load_x(tile_at(1), xa);
+    ring_barrier();   // first tile staged (and the bias table written)
+    int i = 0;
+    for (; i < n; i += 2) {
+        step(i, 0, xa, xq);
+        step(i + 1, 1, xq, xa);
     }
+    // the last staged tile
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_rows(tile_at(i - 1) * BM, k);
     ovf.flush(a.ovf);
 }
 
 bool conv1x1_wregd_admissible(const ConvArgs& a) {
     return a.x2 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.OH && a.W == a.OW && !a.res &&
-           a.ksplit <= 1 && a.Cout % 256 == 0 && a.Cin == 128 && a.Cin2 == 256 && a.Ktot == a.Cin + a.Cin2;
+           a.ksplit <= 1 && a.OW > 1 && a.Cout % 256 == 0 && a.Cin == 128 && a.Cin2 == 256 && a.Ktot == a.Cin + a.Cin2;
 }
 
 template <class DT, int KB1, int KB2>
 static hipError_t launch_wregd(const ConvArgs& a, hipStream_t stream) {
     constexpr int XBUF = (KB1 + KB2) * 64 * 128;
-    constexpr int LDS = 2 * XBUF + 64 * (256 * 2 + 16);
+    constexpr int LDS = 2 * XBUF + 64 * 256 * 2 + 256 * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv1x1_wregd_kernel<DT, KB1, KB2>;
     static std::atomic<uint64_t> attr_done{0};
