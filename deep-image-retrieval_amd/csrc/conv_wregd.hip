@@ -4,17 +4,19 @@
 // block of layer2 (dirtorch/nets/backbones/resnet.py:78-85 with :134-141) as ONE GEMM whose K runs over two tensors,
 // K = 128 (t2) + 256 (the block input, every second pixel of every second row) -> 512 channels.  On the persistent
 // 256 x 256 tile (conv_persist.hip DUAL) this launch is six K-steps per tile between a fill and a 128 KB epilogue and
-// re-fetches its 196 KB weight slice from L2 for every 256 pixels: 0.30 ms at batch 32 = 0.39 of the HBM roof.  K is
+// re-fetches its 196 KB weight slice from L2 for every 256 pixels: 0.33 ms at batch 32 = 0.35 of the HBM roof.  K is
 // short, so - as in conv_wreg.hip - a wave KEEPS its weights: 32 output channels x 384 inputs are 24 MFMA A-fragments
-// = 96 VGPRs; a persistent 8-wave workgroup owns 256 consecutive output channels and streams 64-pixel tiles of the two
-// sources (16 + 32 KB, double-buffered, staged through registers), shared by all eight waves.  The pixel operand is
-// read Cout / 256 = 2 times (the second time from the XCD's L2: the two channel slices of a pixel tile are neighbours
-// in the XCD-aware order), the weights once per workgroup.
+// = 96 VGPRs; a persistent workgroup owns 256 consecutive output channels and streams 64-pixel tiles of the two
+// sources (16 + 32 KB, double-buffered in LDS, two more tiles in flight in registers).  The pixel operand is read
+// Cout / 256 = 2 times (the second time from the XCD's L2: the two channel slices of a pixel tile are neighbours in the
+// XCD-aware order), the weights once per workgroup.  The work is split by wave ROLE (eight consumers, four memory
+// waves: the kernel comment below); how the kernel got there, with the phase builds of every form, is
+// profiles/r06_wregd.txt - 0.24 ms inside the network.
 //
-// Epilogue: accumulators start at the bias (conv_persist.hip's convention: same MFMA, same K order - the sums are those
-// of the DUAL ring kernel bit for bit); every lane applies ReLU, packs its 16 channels of one pixel and writes them to a
-// [64 px][256 ch] 16-bit staging tile; after one barrier the whole workgroup stores the tile as 512-byte pixel rows
-// (16 bytes per lane, consecutive lanes consecutive chunks).
+// Accumulators start at the bias (conv_persist.hip's convention: same MFMA, same K order - the sums are those of the DUAL
+// ring kernel bit for bit); a consumer lane applies ReLU, packs its 16 channels of one pixel and writes them to a
+// [64 px][256 ch] 16-bit staging tile (16-byte chunks XOR-swizzled by the pixel row); the memory waves store the tile as
+// 512-byte pixel rows (16 bytes per lane, consecutive lanes consecutive chunks).
 #include "dir_common.h"
 #include "conv_igemm.h"
 
