@@ -477,11 +477,11 @@ static const ConvVariant kVariants[] = {
     // pipe - the 3x3 convs of layer3/4
     DIR_VARIANT(256, 256, 4, 4, 2, 64, "256x256_w4x4"),
     // the small-map regime (batch 1 / 224^2 buckets: 1 000 - 13 000 pixels per layer): 64x64 tiles give every CU one even at
-    // 4 096 pixels x 256 channels, and an 8-slot ring (six 16 KB stages in flight) covers the L2 round trip that a 2- or 4-slot
-    // ring of such short stages exposes on every K-step
+    // 4 096 pixels x 256 channels.  _s4 (64 KB: two workgroups per CU - what forwards overlapping on several streams need) is the
+    // picker's choice: batch 1 at 1024^2 768 -> 799 img/s on one stream, 1 320 -> 1 366 on four; _s8 (six 16 KB stages in flight,
+    // 128 KB) is 1 % better on one stream and 20 % worse on four (806 / 1 075, gpurun_out/r6smallab2) - a tuner candidate
     DIR_VARIANT_SK(64, 64, 2, 2, 8, 64, "64x64_w2x2_s8"),
-    DIR_VARIANT_SK(64, 128, 2, 2, 6, 64, "64x128_w2x2_s6"),
-    DIR_VARIANT_SK(128, 64, 2, 2, 6, 64, "128x64_w2x2_s6"),
+    DIR_VARIANT_SK(64, 64, 2, 2, 4, 64, "64x64_w2x2_s4"),
     // 3x3 stride-1 from an LDS-resident input patch (conv_patch.hip): 8x32 pixels x all channels
     {"256x64_patch3x3", 256, 64, 256, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
     {"256x128_patch3x3", 256, 128, 512, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 1, {nullptr, nullptr}, {nullptr, nullptr}},
@@ -616,6 +616,21 @@ int conv_pick_variant(const ConvArgs& a) {
         if (a.R * a.S > 1 && a.stride > 1) c[n++] = {"256x128_w4x2_s3", 1};
         c[n++] = {"256x128_w4x2_s3_k32", 2}, c[n++] = {"128x128_w2x2", 1};
         c[n++] = {T >= 8 ? "64x128_w2x2_s4" : "64x128_w2x2", 1}, c[n++] = {"64x64_w2x1", 1};
+    }
+    // The small-map regime (round 6, distilled from the tuner at batch 1 / batch 4 of 1024^2 and ResNet-50 at 64 x 224^2,
+    // gpurun_out/r6small): when a long-K layer with 256+ outputs cannot fill the chip with 256-wide tiles and 128 x 128 tiles give
+    // it less than two rounds, 64 x 128 tiles (48 KB: two workgroups per CU, one's fill under the other's MFMAs) are 8-10 %
+    // faster (same box: +0.5 % on the whole step at batch 4 and on config A); below ~250 of those, 64 x 64 tiles on a 4-slot ring
+    // (one per CU at 4 096 pixels x 256 channels, 64 KB so that a second stream's workgroup fits beside it).
+    if (!env().no_smallmap && a.Cout % 256 == 0 && T >= 6 && !(a.R * a.S > 1 && a.Cin >= 128 && !env().no_patchw &&
+                                         conv_patch3x3w_admissible(a) && (long)ceil_div(a.M, 512) * (a.Cout / 128) >= 192)) {
+        const long t256 = (long)ceil_div(a.M, 256) * (a.Cout / 256), t128 = (long)ceil_div(a.M, 128) * (a.Cout / 128);
+        const long t64x128 = (long)ceil_div(a.M, 64) * (a.Cout / 128), t64 = (long)ceil_div(a.M, 64) * (a.Cout / 64);
+        if (t256 < 192 && t128 < 512) {
+            const int v1 = find_variant("64x128_w2x2"), v2 = find_variant("64x64_w2x2_s4");
+            if (t64x128 >= 256 && v1 >= 0 && conv_variant_admissible(v1, a)) return v1;
+            if (t64x128 < 192 && t64 >= 192 && v2 >= 0 && conv_variant_admissible(v2, a)) return v2;
+        }
     }
     int last = -1, prev = -1;
     for (int i = 0; i < n; ++i) {

@@ -182,11 +182,14 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     for name, s in shapes.items():
         assert pick(32, *s) == (batch32[name], 1), name
     batch1 = {    # small M: deep-ring small tiles, split-K where even those leave CUs idle
-        'l2.conv2': ('64x128_w2x2_s4', 1), 'l3.conv1': ('64x128_w2x2_s4', 1), 'l3.conv2': ('64x128_w2x2_s4', 1),
+        'l2.conv2': ('64x128_w2x2_s4', 1), 'l3.conv1': ('64x64_w2x2_s4', 1), 'l3.conv2': ('64x64_w2x2_s4', 1),   # (round 6: one 64 x 64 tile per CU, 64 KB of LDS)
         'l3.conv3': ('128x128_w2x2', 1), 'l4.conv1': ('64x128_w2x2', 8), 'l4.conv2': ('64x128_w2x2', 8),
     }
     for name, want in batch1.items():
         assert pick(1, *shapes[name]) == want, name
+    # between the two regimes (batch 4 here; ResNet-50 at 64 x 224^2 has the same pixel counts): 64 x 128 tiles, two workgroups per CU
+    assert pick(4, *shapes['l3.conv1']) == ('64x128_w2x2', 1) and pick(4, *shapes['l3.conv2']) == ('64x128_w2x2', 1)
+    assert pick(8, *shapes['l3.conv2']) == ('128x128_w2x2', 1)
     # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
     # the strided 3x3 of layer2.0 (256^2 -> 128^2): the BK = 64 tile
     assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_w4x2_s3', 1)
