@@ -398,6 +398,8 @@ hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
 #ifdef DIR_EXPERIMENTS
     if (a.Cin == 256) return conv_seam3_launch(a, dtype, stream);
 #endif
+    // the DS form with its work split by wave role (conv_c3c1lc.hip, round 6; DIRTORCH_AMD_NO_C3C1LC: the one-role kernel below)
+    if (a.x2 && !env().no_c3c1lc && conv_c3c1ds_lc_admissible(a)) return conv_c3c1ds_lc_launch(a, dtype, stream);
     if (a.w_lo) {   // DIR_FP16P: conv3's (+ downsample's) weights are pairs; conv1's are when they belong to layer1 too
         if (dtype != DIR_FP16) return hipErrorInvalidValue;
         if (a.x2) return a.w2_lo ? launch_c3c1<FP16, 64, true, 64, true, true>(a, stream) : hipErrorInvalidValue;

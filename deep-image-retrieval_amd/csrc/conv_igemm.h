@@ -92,6 +92,8 @@ hipError_t conv1x1_wreg_launch(const ConvArgs& a, int dtype, hipStream_t stream)
 bool conv_seam3_admissible(const ConvArgs& a);
 hipError_t conv_seam3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_c3c1_admissible(const ConvArgs& a);
+bool conv_c3c1ds_lc_admissible(const ConvArgs& a);   // the DS seam, loader / consumer form (conv_c3c1lc.hip)
+hipError_t conv_c3c1ds_lc_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 hipError_t conv_c3c1_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3s_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3s_launch(const ConvArgs& a, int dtype, hipStream_t stream);

@@ -41,6 +41,7 @@ static Env read_env() {
     e.no_wreg = on("DIRTORCH_AMD_NO_WREG");
     e.no_wregd = on("DIRTORCH_AMD_NO_WREGD");
     e.no_smallmap = on("DIRTORCH_AMD_NO_SMALLMAP");
+    e.no_c3c1lc = on("DIRTORCH_AMD_NO_C3C1LC");
     e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");
     e.no_x3 = on("DIRTORCH_AMD_NO_X3");
     e.no_patchs = on("DIRTORCH_AMD_NO_PATCHS");

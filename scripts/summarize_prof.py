@@ -68,6 +68,9 @@ def short(name):
     if m:   # <DT, P, DS, P2[, WP3, WP1]>: wp = paired weights (DIR_FP16P)
         return 'conv_c3c1<%s%s%s>[%s]' % (m.group(2), ',ds' if m.group(3) == 'true' else '',
                                           ',wp' if m.group(5) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv_c3c1ds_lc_kernel<dir::(\w+), (\w+)>', name)
+    if m:   # the DS seam with loader / consumer roles (csrc/conv_c3c1lc.hip): <DT, WP>
+        return 'conv_c3c1<64,ds%s>[%s]' % (',wp' if m.group(2) == 'true' else '', m.group(1).lower())
     m = re.search(r'conv_seam3_kernel<dir::(\w+)>', name)
     if m:   # the layer3 seam (csrc/conv_seam3.hip), opt-in
         return 'conv_seam3<256>[%s]' % m.group(1).lower()

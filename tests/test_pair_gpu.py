@@ -170,6 +170,42 @@ def test_seam_with_paired_weights(B, H, W, P2, w1_pair):
     assert torch.equal(y0, ys) and torch.equal(t0, ts)
 
 
+@pytest.mark.parametrize('B,H,W', [(1, 9, 13), (3, 37, 41), (8, 256, 256)], ids=['two tiles', 'ragged, one tile per workgroup', 'batch 8 of 1024^2'])
+def test_downsample_seam_roles_split_equals_the_one_role_kernel(B, H, W, monkeypatch):
+    """conv_c3c1lc.hip (round 6: eight consumer waves, four memory waves, outputs handed to the memory waves through LDS
+    tiles) against conv_c3c1.hip's DS form (DIRTORCH_AMD_NO_C3C1LC=1), bit for bit, paired and plain: odd / even tile counts
+    per workgroup (the counted pair loop stores an odd last tile twice), a ragged last tile, and 2 048 tiles on 256
+    workgroups; the paired form also against fp64 on a sample of pixels."""
+    from dirtorch_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(79)
+    h = lambda *sh, s=1.0: (torch.randn(*sh, generator=g, device='cuda') * s).half()      # noqa: E731
+    t2, xh, xl = torch.relu(h(B, H, W, 64)), torch.relu(h(B, H, W, 64)), h(B, H, W, 64, s=2.0 ** -11)
+    wh, wl = h(256, 128, s=0.06), h(256, 128, s=0.06 * 2.0 ** -11)
+    w1h, w1l = h(64, 256, s=0.04), h(64, 256, s=0.04 * 2.0 ** -11)
+    b, b1 = torch.randn(256, generator=g, device='cuda'), torch.randn(64, generator=g, device='cuda')
+
+    def both():
+        yp, tp = ops.conv_c3c1_ds_wpair(t2, (xh, xl), (wh, wl), b, (w1h, w1l), b1)
+        ys, ts = ops.conv_c3c1_ds(t2, xh, wh, b, w1h, b1)
+        yb, tb = ops.conv_c3c1_ds(t2.bfloat16(), xh.bfloat16(), wh.bfloat16(), b, w1h.bfloat16(), b1)
+        return yp, tp, ys, ts, yb, tb
+    new = both()
+    monkeypatch.setenv('DIRTORCH_AMD_NO_C3C1LC', '1')
+    old = both()
+    monkeypatch.delenv('DIRTORCH_AMD_NO_C3C1LC')
+    for i, (u, v) in enumerate(zip(new, old)):
+        assert torch.equal(u, v), i
+    assert torch.isfinite(new[0].float()).all() and float(new[0].float().abs().max()) > 0.5
+    d = lambda t: t.double()      # noqa: E731
+    idx = torch.randint(0, B * H * W, (min(4096, B * H * W),), device='cuda', generator=g)
+    f = lambda t: d(t.reshape(-1, t.shape[-1])[idx])      # noqa: E731
+    wf = d(wh) + d(wl)
+    yref = torch.relu(f(t2) @ wf[:, :64].T + f(xh) @ wf[:, 64:].T + f(xl) @ d(wh)[:, 64:].T + d(b))
+    assert float((f(new[0]) - yref).abs().max()) <= 1.01 * 2.0 ** -11 * float(yref.abs().max())
+    tref = torch.relu(f(new[0]) @ (d(w1h) + d(w1l)).T + d(b1))
+    assert float((f(new[1]) - tref).abs().max()) <= 1.01 * 2.0 ** -11 * float(tref.abs().max()) + 1e-5
+
+
 @pytest.mark.parametrize('B,H,W', [(2, 16, 24), (1, 9, 13)], ids=['layer1.0', 'ragged'])
 def test_downsample_seam_with_paired_weights_and_paired_block_input(B, H, W):
     """dir_conv_c3c1_ds_wpair: y = relu([w3 | wds] . [t2 ; x] + b), x = the stem's pooled output as a PAIR.  Product terms
