@@ -505,6 +505,9 @@ static const ConvVariant kVariants[] = {
 #endif
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
     {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}, {nullptr, nullptr}},
+    // the deep-X ring with loader / consumer wave roles (eight consumers, four loaders): 1x1 without a residual, and its two-source form
+    {"256x256_lc1x1", 256, 256, 768, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 10, {nullptr, nullptr},
+     {conv1x1_lc_dual_bf16, conv1x1_lc_dual_fp16}},
     // the two-source GEMM of layer2's first block (K = 128 + 256) with 32 output channels x 384 inputs per wave held in VGPRs,
     // 256 channels per workgroup (conv_wregd.hip); a launch_dual-only entry
     {"64x256_wregd1x1", 64, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 9, {nullptr, nullptr},
@@ -528,6 +531,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
 #endif
     if (cv.kind == 8) return conv_patch64_lc_admissible(a);
+    if (cv.kind == 10) return a.x2 == nullptr && conv1x1_lc_admissible(a);
     if (cv.kind == 9) return conv1x1_wregd_admissible(a);   // (two-source shapes only: never true for a plain conv)
     if (a.Cout % cv.BN != 0) return false;
     if (a.Cin == 16 && cv.launch16[0] == nullptr) return false;
@@ -602,6 +606,7 @@ int conv_pick_variant(const ConvArgs& a) {
 #ifdef DIR_EXPERIMENTS
         if (a.R * a.S == 1 && !a.res && env().experiments) c[n++] = {"128x256_ring1x1", 1};
 #endif
+        if (a.R * a.S == 1 && !a.res && env().lc1x1) c[n++] = {"256x256_lc1x1", 1};   // (A/B: DIRTORCH_AMD_LC1X1)
         c[n++] = {a.R * a.S > 1 ? "256x256_w4x4" : (x3 ? "256x256_persist1x1_x3" : "256x256_persist1x1"), 1};
         c[n++] = {"256x256_w4x2", 1}, c[n++] = {"128x128_w2x2", 1};
         // small M (batch 1 at the deep stages): the 4-slot ring hides the fill latency of a long K
@@ -668,6 +673,13 @@ int conv_pick_dual_variant(const ConvArgs& a, bool any_size) {
             return v;
     }
     if (a.Cout % 256 != 0 || (!any_size && (long)ceil_div(a.M, 256) * (a.Cout / 256) < 192)) return -1;
+    // (conv_persistlc.hip - the same ring with loader / consumer wave roles - measured on layers 3-4, gpurun_out/r6lc1x1*: 4-8 % off the
+    // launch by per-layer events, nothing on the whole step in two same-box A/Bs, and 5-15 % SLOWER on the plain 1x1 convs inside the
+    // network; an opt-in (DIRTORCH_AMD_LC1X1) and a tuner candidate, not a default)
+    if (env().lc1x1) {
+        const int vl = find_variant("256x256_lc1x1");
+        if (vl >= 0 && conv1x1_lc_admissible(a)) return vl;
+    }
     const int v = find_variant("256x256_persist1x1_x3");
     if (v < 0 || kVariants[v].launch_dual[0] == nullptr) return -1;
     return v;
@@ -755,7 +767,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
     if (a.x2) {   // two-source K: conv3 + downsample in one GEMM
         if (variant < 0) variant = conv_pick_dual_variant(a);
         if (variant < 0 || variant >= kNumVariants || kVariants[variant].launch_dual[0] == nullptr ||
-            a.Cout % kVariants[variant].BN != 0 || (kVariants[variant].kind == 9 && !conv1x1_wregd_admissible(a)) || a.R != 1 || a.S != 1 || a.stride != 1 || a.res || a.ksplit > 1 ||
+            a.Cout % kVariants[variant].BN != 0 || (kVariants[variant].kind == 9 && !conv1x1_wregd_admissible(a)) || (kVariants[variant].kind == 10 && !conv1x1_lc_admissible(a)) || a.R != 1 || a.S != 1 || a.stride != 1 || a.res || a.ksplit > 1 ||
             a.Cin2 % 64 != 0 || a.Ktot != a.Cin + a.Cin2 || ((uintptr_t)a.x2 & 15) ||
             (long)a.B * a.H2 * a.W2 * a.Cin2 >= (1L << 30))
             return fail(DIR_ERR_INVALID, "conv: no two-source form for this shape / variant");
@@ -785,6 +797,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
                    : cv.kind == 7 ? conv1x1_ring_launch(a, dtype, stream)
 #endif
                    : cv.kind == 8 ? conv_patch64_lc_launch(a, dtype, stream)
+                   : cv.kind == 10 ? conv1x1_lc_launch(a, dtype, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)

@@ -42,6 +42,7 @@ static Env read_env() {
     e.no_wregd = on("DIRTORCH_AMD_NO_WREGD");
     e.no_smallmap = on("DIRTORCH_AMD_NO_SMALLMAP");
     e.no_c3c1lc = on("DIRTORCH_AMD_NO_C3C1LC");
+    e.lc1x1 = on("DIRTORCH_AMD_LC1X1");
     e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");
     e.no_x3 = on("DIRTORCH_AMD_NO_X3");
     e.no_patchs = on("DIRTORCH_AMD_NO_PATCHS");
