@@ -70,6 +70,7 @@ struct ConvVariant {
                                // 7 = persistent 128x256 1x1 without a residual, one K ring over all tiles of a workgroup (conv_ring.hip)
                                // 8 = 64 -> 64 channel 3x3 with the filter resident in LDS, loader / consumer waves (conv_patchlc.hip)
                                // 9 = two-source 1x1 (launch_dual only) with register-stationary weights (conv_wregd.hip)
+                               // 11 = 64 x 64 tiles for small maps: loader / consumer waves on LDS counters (conv_small.hip; `stages` = ring depth)
                                // 10 = kind 4's ring with loader / consumer wave roles, 1x1 without a residual and its two-source form (conv_persistlc.hip)
     ConvLaunchFn launch_sk[2]; // split-K instantiation (ConvArgs::ksplit > 1), or nullptr
     ConvLaunchFn launch_dual[2]; // two-source K instantiation (ConvArgs::x2: conv3 + downsample in one GEMM), or nullptr
@@ -84,6 +85,8 @@ hipError_t conv_patch64_lc_launch(const ConvArgs& a, int dtype, hipStream_t stre
 bool conv1x1_ring_admissible(const ConvArgs& a);
 hipError_t conv1x1_ring_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv1x1_wreg_admissible(const ConvArgs& a);
+bool conv_small_admissible(const ConvArgs& a);      // small maps: 64 x 64 tiles, four consumer + four loader waves, no workgroup barrier (conv_small.hip)
+hipError_t conv_small_launch(const ConvArgs& a, int dtype, int nst, hipStream_t stream);
 bool conv1x1_lc_admissible(const ConvArgs& a);      // the persistent 256 x 256 ring with loader / consumer roles (conv_persistlc.hip)
 hipError_t conv1x1_lc_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 hipError_t conv1x1_lc_dual_bf16(const ConvArgs& a, hipStream_t stream);

@@ -505,6 +505,10 @@ static const ConvVariant kVariants[] = {
 #endif
     // persistent, 64 output channels x K <= 256 per wave held in VGPRs, only pixels stream (conv_wreg.hip)
     {"64x512_wreg1x1", 64, 512, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 3, {nullptr, nullptr}, {nullptr, nullptr}},
+    // small maps (batch 1 at native size): 64 x 64 tiles, four consumer + four loader waves that meet on LDS counters, no workgroup
+    // barrier in the loop (conv_small.hip); _s4 = 64 KB (two workgroups per CU), _s8 = 128 KB
+    {"64x64_small_s8", 64, 64, 512, 8, 64, {nullptr, nullptr}, {nullptr, nullptr}, 11, {nullptr, nullptr}, {nullptr, nullptr}},
+    {"64x64_small_s4", 64, 64, 512, 4, 64, {nullptr, nullptr}, {nullptr, nullptr}, 11, {nullptr, nullptr}, {nullptr, nullptr}},
     // the deep-X ring with loader / consumer wave roles (eight consumers, four loaders): 1x1 without a residual, and its two-source form
     {"256x256_lc1x1", 256, 256, 768, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 10, {nullptr, nullptr},
      {conv1x1_lc_dual_bf16, conv1x1_lc_dual_fp16}},
@@ -531,6 +535,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
 #endif
     if (cv.kind == 8) return conv_patch64_lc_admissible(a);
+    if (cv.kind == 11) return conv_small_admissible(a);
     if (cv.kind == 10) return a.x2 == nullptr && conv1x1_lc_admissible(a);
     if (cv.kind == 9) return conv1x1_wregd_admissible(a);   // (two-source shapes only: never true for a plain conv)
     if (a.Cout % cv.BN != 0) return false;
@@ -798,6 +803,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
 #endif
                    : cv.kind == 8 ? conv_patch64_lc_launch(a, dtype, stream)
                    : cv.kind == 10 ? conv1x1_lc_launch(a, dtype, stream)
+                   : cv.kind == 11 ? conv_small_launch(a, dtype, cv.stages, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)
                                   : (cin16 ? cv.launch16 : cv.launch)[dtype](a, stream);
     if (e != hipSuccess)
