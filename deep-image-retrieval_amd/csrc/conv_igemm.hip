@@ -509,6 +509,7 @@ static const ConvVariant kVariants[] = {
     // barrier in the loop (conv_small.hip); _s4 = 64 KB (two workgroups per CU), _s8 = 128 KB
     {"64x64_small_s8", 64, 64, 512, 8, 64, {nullptr, nullptr}, {nullptr, nullptr}, 11, {nullptr, nullptr}, {nullptr, nullptr}},
     {"64x64_small_s4", 64, 64, 512, 4, 64, {nullptr, nullptr}, {nullptr, nullptr}, 11, {nullptr, nullptr}, {nullptr, nullptr}},
+    {"64x64_small_s4k2", 64, 64, 512, 5, 64, {nullptr, nullptr}, {nullptr, nullptr}, 11, {nullptr, nullptr}, {nullptr, nullptr}},   // 4 slots x 2 K-steps per stage
     // the deep-X ring with loader / consumer wave roles (eight consumers, four loaders): 1x1 without a residual, and its two-source form
     {"256x256_lc1x1", 256, 256, 768, 3, 64, {nullptr, nullptr}, {nullptr, nullptr}, 10, {nullptr, nullptr},
      {conv1x1_lc_dual_bf16, conv1x1_lc_dual_fp16}},
@@ -535,7 +536,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
 #endif
     if (cv.kind == 8) return conv_patch64_lc_admissible(a);
-    if (cv.kind == 11) return conv_small_admissible(a);
+    if (cv.kind == 11) return conv_small_admissible(a) && (cv.stages != 5 || (a.Ktot / 64) % 2 == 0);
     if (cv.kind == 10) return a.x2 == nullptr && conv1x1_lc_admissible(a);
     if (cv.kind == 9) return conv1x1_wregd_admissible(a);   // (two-source shapes only: never true for a plain conv)
     if (a.Cout % cv.BN != 0) return false;

@@ -43,15 +43,20 @@ __device__ __forceinline__ void lds_write1_raw(uint32_t addr, int v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
-template <class DT, int NST>
+// KPS = K-steps of 64 per ring stage (one hand-off per stage): 1, or 2 (32 KB stages: half the hand-offs, the same bytes)
+template <class DT, int NST, int KPS>
 __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
     constexpr int BM = 64, BN = 64;
-    constexpr int XS = BM * 128, STAGE = (BM + BN) * 128;   // 8 KB + 8 KB
-    constexpr int LAG = NST - 2;                             // stages a loader keeps in flight
+    constexpr int XS = BM * 128, KSTEP = (BM + BN) * 128, STAGE = KPS * KSTEP;   // per K-step: 8 KB + 8 KB
+    // stages a loader keeps in flight behind its counted wait.  It publishes stage c when it issues stage c + LAG, and it may issue
+    // that one only when the consumers have left slot (c + LAG) % NST - so NST - LAG - 1 stages of slack decouple the two roles.
+    // (LAG = NST - 2, the first form, left ONE: every hand-off then sat on a poll -> issue -> poll round trip, ~0.19 us per stage at
+    // any ring depth.)
+    constexpr int LAG = NST >= 8 ? 3 : 1;
     constexpr int CNT_OFF = NST * STAGE;                     // [0..3] landed (per loader), [4..7] consumed (per consumer), 16-byte aligned
     constexpr int SPIN_LIMIT = 1 << 23;
     typedef typename DT::frag_t frag_t;
-    static_assert(NST >= 3 && 4 * LAG <= 63, "ring depth");
+    static_assert(NST >= 3 && 4 * KPS * LAG <= 63, "ring depth");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const cnt = (int*)(smem + CNT_OFF);
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
     const int lrow = lane & 31, lhi = lane >> 5;
 
     const int ntiles = a.tiles_m * a.tiles_n;
-    const int T = a.T;
+    const int T = a.T / KPS;   // ring stages per tile (the launcher checks T % KPS == 0)
     const int first = xcd_remap(blockIdx.x, gridDim.x);
     if (first >= ntiles) return;
     const int my_tiles = (ntiles - first + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -138,34 +143,37 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            char* dst = smem + slot * STAGE + (2 * l) * 1024;
-            const int koff = ((r * a.W + s) * a.Cin + cc * 64) * 2;
-            const int wstep = tap * (a.Cin / 64) + cc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t v = ((xmask[i] >> tap) & 1u) ? (uint32_t)(xbase[i] + koff) : kOOBs;
-                dma16s(rsrc_x, dst + i * 1024, v, 0);
-            }
+            for (int kk = 0; kk < KPS; ++kk) {
+                char* dst = smem + slot * STAGE + kk * KSTEP + (2 * l) * 1024;
+                const int koff = ((r * a.W + s) * a.Cin + cc * 64) * 2;
+                const int wstep = tap * (a.Cin / 64) + cc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dma16s(rsrc_w, dst + XS + i * 1024, wvoff[i], wstep * 128);
-            slot = slot + 1 == NST ? 0 : slot + 1;
-            // K order: channel slice outermost, taps innermost (conv_igemm.hip)
-            ++tap;
-            if (++s == a.S) {
-                s = 0;
-                if (++r == a.R) {
-                    r = 0;
-                    tap = 0;
-                    ++cc;
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t v = ((xmask[i] >> tap) & 1u) ? (uint32_t)(xbase[i] + koff) : kOOBs;
+                    dma16s(rsrc_x, dst + i * 1024, v, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dma16s(rsrc_w, dst + XS + i * 1024, wvoff[i], wstep * 128);
+                // K order: channel slice outermost, taps innermost (conv_igemm.hip)
+                ++tap;
+                if (++s == a.S) {
+                    s = 0;
+                    if (++r == a.R) {
+                        r = 0;
+                        tap = 0;
+                        ++cc;
+                    }
                 }
             }
+            slot = slot + 1 == NST ? 0 : slot + 1;
             if (++t == T) {
                 t = 0, tap = 0, cc = 0, r = 0, s = 0;
                 tile += (int)gridDim.x;
                 if (tile < ntiles) tile_offsets(tile);
             }
             if (g >= LAG) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * LAG) : "memory");   // my part of stage g - LAG has landed
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * KPS * LAG) : "memory");   // my part of stage g - LAG has landed
                 if (lane == 0) lds_write1_raw(cnt_lds + 4 * l, g - LAG + 1);
             }
         }
@@ -183,42 +191,65 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
     const int xfrag = (cm * 32) * 128;
     const int wfrag = XS + (cn * 32) * 128;
     Ovf<DT> ovf;
-    int tile = first, slot = 0, g = 0;
-    for (int ti = 0; ti < my_tiles; ++ti, tile += (int)gridDim.x) {
+    // The consumer's stream is software-pipelined over the ring (profiles/r06_small_map.txt: with poll -> fragment reads -> MFMAs ->
+    // flag strictly in sequence a hand-off cost ~0.19 us, more than the stage's bytes): the fragments of stage g + 1 are requested
+    // before the MFMAs of stage g are issued (two register sets), the loaders' words are read only when the cached count does not
+    // cover the stage, and a slot is given back as soon as its fragment reads have been ISSUED - LDS executes a wave's
+    // instructions in order, so the flag write cannot pass them, and the loader's LDS-DMA into the slot is issued only after it
+    // has seen the flag.
+    int landed = 0;   // stages every loader is known to have landed
+    auto ensure = [&](int need) {
+        if (landed >= need) return;
+        for (int spins = 0;; ++spins) {
+            const int v0 = __hip_atomic_load(cnt + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int v1 = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int v2 = __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int v3 = __hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            landed = min(min(v0, v1), min(v2, v3));
+            if (landed >= need) break;
+            if (spins > SPIN_LIMIT) {
+                if (a.ovf && lane == 0) atomicOr(a.ovf, 2);
+                landed = need;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    frag_t wfA[4 * KPS], xfA[4 * KPS], wfB[4 * KPS], xfB[4 * KPS];
+    auto read_frags = [&](int slot_, frag_t* wf, frag_t* xf) {
+#pragma unroll
+        for (int kk = 0; kk < KPS; ++kk) {
+            const char* stage = smem + slot_ * STAGE + kk * KSTEP;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wf[kk * 4 + ks] = *(const frag_t*)(stage + wfrag + loff[ks]);
+                xf[kk * 4 + ks] = *(const frag_t*)(stage + xfrag + loff[ks]);
+            }
+        }
+    };
+    int tile = first, t = 0;
+    f32x16_t acc0, acc1;
+    f32x4_t b4[4];
+    u32x4_t rres[2] = {};
+    int n_wave = 0, m = 0;
+    bool mok = false;
+    auto tile_begin = [&]() {
         const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-        const int n_wave = tile_n * BN + cn * 32;
-        const int m = tile_m * BM + cm * 32 + lrow;
+        n_wave = tile_n * BN + cn * 32;
+        m = tile_m * BM + cm * 32 + lrow;
+        mok = m < a.M;
         // requested now, used in the epilogue: the bias of this lane's 16 channels and its two residual pieces
-        f32x4_t b4[4];
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) b4[gg] = *(const DIR_GLOBAL f32x4_t*)(a.bias + n_wave + 8 * gg + 4 * lhi);
-        u32x4_t rres[2] = {};
-        const bool mok = m < a.M;
         if (a.res && mok) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) rres[h] = gload16(a.res + ((size_t)m * a.Cout + n_wave + h * 16 + lhi * 8));
         }
-        f32x16_t acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc0[e] = 0.f, acc1[e] = 0.f;
-        for (int t = 0; t < T; ++t, ++g) {
-            await4(cnt, g + 1);   // every loader's part of stage g has landed
-            const char* stage = smem + slot * STAGE;
-            frag_t wf[4], xf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wf[ks] = *(const frag_t*)(stage + wfrag + loff[ks]);
-                xf[ks] = *(const frag_t*)(stage + xfrag + loff[ks]);
-            }
-            acc0 = DT::mfma32(wf[0], xf[0], acc0);
-            acc1 = DT::mfma32(wf[1], xf[1], acc1);
-            acc0 = DT::mfma32(wf[2], xf[2], acc0);
-            acc1 = DT::mfma32(wf[3], xf[3], acc1);
-            // (the fragment reads above have returned - their MFMAs were issued - before the slot is given back)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(cnt + 4 + wave, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            slot = slot + 1 == NST ? 0 : slot + 1;
-        }
+    };
+    auto tile_end = [&]() {
         // ---- epilogue: the two partial sums + bias (+ residual), ReLU, pack; v_permlane32_swap pairs the half-waves' 8-byte
         //      pieces into 16-byte stores.  acc[4 gg + e] = channel 8 gg + 4 lhi + e of pixel lrow.
 #pragma unroll
@@ -260,6 +291,37 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
                 ovf.see(ov);
             }
         }
+    };
+    // one step = stage g from register set `cur`, stage g + 1 requested into `nxt`
+    auto step = [&](int g, frag_t* wfc, frag_t* xfc, frag_t* wfn, frag_t* xfn) {
+        // stage g's fragment reads were issued one step ago: its slot goes back now (the empty asm keeps the compiler from sinking
+        // those reads below the flag; the hardware executes this wave's LDS instructions in order)
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(cnt + 4 + wave, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (g + 1 < total) {
+            ensure(g + 2);
+            read_frags((g + 1) % NST, wfn, xfn);
+        }
+        if (t == 0) tile_begin();
+#pragma unroll
+        for (int kk = 0; kk < KPS; ++kk) {
+            acc0 = DT::mfma32(wfc[kk * 4 + 0], xfc[kk * 4 + 0], acc0);
+            acc1 = DT::mfma32(wfc[kk * 4 + 1], xfc[kk * 4 + 1], acc1);
+            acc0 = DT::mfma32(wfc[kk * 4 + 2], xfc[kk * 4 + 2], acc0);
+            acc1 = DT::mfma32(wfc[kk * 4 + 3], xfc[kk * 4 + 3], acc1);
+        }
+        if (++t == T) {
+            tile_end();
+            t = 0;
+            tile += (int)gridDim.x;
+        }
+    };
+    ensure(1);
+    read_frags(0, wfA, xfA);
+    for (int g = 0; g < total; g += 2) {
+        step(g, wfA, xfA, wfB, xfB);
+        if (g + 1 < total) step(g + 1, wfB, xfB, wfA, xfA);
     }
     ovf.flush(a.ovf);
 }
@@ -269,11 +331,12 @@ bool conv_small_admissible(const ConvArgs& a) {
            (long)a.B * a.H * a.W * a.Cin < (1L << 30) && (long)a.M * a.Cout < (1L << 30);
 }
 
-template <class DT, int NST>
+template <class DT, int NST, int KPS = 1>
 static hipError_t launch_small(const ConvArgs& a, hipStream_t stream) {
-    constexpr int LDS = NST * 128 * 128 + 64;
+    constexpr int LDS = NST * KPS * 128 * 128 + 64;
     static_assert(LDS <= 160 * 1024, "LDS map");
-    auto kern = conv_small_kernel<DT, NST>;
+    if ((a.Ktot / 64) % KPS != 0) return hipErrorInvalidValue;
+    auto kern = conv_small_kernel<DT, NST, KPS>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -299,6 +362,7 @@ static hipError_t launch_small(const ConvArgs& a, hipStream_t stream) {
 
 hipError_t conv_small_launch(const ConvArgs& a, int dtype, int nst, hipStream_t stream) {
     if (nst == 4) return dtype == DIR_BF16 ? launch_small<BF16, 4>(a, stream) : launch_small<FP16, 4>(a, stream);
+    if (nst == 5) return dtype == DIR_BF16 ? launch_small<BF16, 4, 2>(a, stream) : launch_small<FP16, 4, 2>(a, stream);   // (table: stages 5 = 4 slots x 2 K-steps)
     return dtype == DIR_BF16 ? launch_small<BF16, 8>(a, stream) : launch_small<FP16, 8>(a, stream);
 }
 

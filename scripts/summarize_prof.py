@@ -96,9 +96,9 @@ def short(name):
     m = re.search(r'conv1x1_wreg_kernel<dir::(\w+), (\d+)>', name)
     if m:
         return 'conv_igemm<64x512_wreg1x1>[%s]' % m.group(1).lower()
-    m = re.search(r'conv_small_kernel<dir::(\w+), (\d+)>', name)
-    if m:   # small maps: 64 x 64 tiles, loader / consumer waves on LDS counters (csrc/conv_small.hip): <DT, NST>
-        return 'conv_igemm<64x64_small_s%s>[%s]' % (m.group(2), m.group(1).lower())
+    m = re.search(r'conv_small_kernel<dir::(\w+), (\d+), (\d+)>', name)
+    if m:   # small maps: 64 x 64 tiles, loader / consumer waves on LDS counters (csrc/conv_small.hip): <DT, NST, KPS>
+        return 'conv_igemm<64x64_small_s%s%s>[%s]' % (m.group(2), 'k2' if m.group(3) == '2' else '', m.group(1).lower())
     m = re.search(r'conv1x1_lc_kernel<dir::(\w+), (\w+)>', name)
     if m:   # the deep-X ring with loader / consumer roles (csrc/conv_persistlc.hip): <DT, DUAL>
         return 'conv_igemm<256x256_lc1x1%s>[%s]' % ('/dual' if m.group(2) == 'true' else '', m.group(1).lower())

@@ -54,6 +54,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
         return k == 3 and stride == 1 and pad == 1 and Cin == Cout == bn
     if 'ring1x1' in name:                # loader / consumer K ring: 1x1 without a residual, 256-channel output tiles
         return k == 1 and pad == 0 and Cout % 256 == 0 and Cout <= 2048 and Cin >= 128 and not has_res
+    if 'small_s4k2' in name:             # conv_small.hip with two K-steps per ring stage: an even number of K-steps
+        return Cout % 64 == 0 and (k * k * Cin // 64) % 2 == 0
     if 'lc1x1' in name:                  # the deep-X ring with loader / consumer roles: stride 1, no residual
         return k == 1 and stride == 1 and pad == 0 and Cout % 256 == 0 and Cin >= 128 and not has_res
     if 'persist1x1_x3' in name:          # the deep-X form has no residual path
