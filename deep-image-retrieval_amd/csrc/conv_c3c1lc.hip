@@ -73,8 +73,16 @@ __global__ void __launch_bounds__(768) conv_c3c1ds_lc_kernel(const ConvArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    // (every spin is bounded: a wave that waits ~0.3 s raises bit 1 of the overflow word and lets go - the results are then garbage
+    // and the host sees the flag; a lost hand-off must not hang the GPU)
     auto await = [&](int* c, int target) {
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        for (int spins = 0; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spins) {
+            if (spins > (1 << 22)) {
+                if (a.ovf && lane == 0) atomicOr(a.ovf, 2);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
 
