@@ -83,6 +83,19 @@ def test_switches_are_read_once_and_reloaded_on_request():
     assert pick() == '512x128_patch3x3w'
 
 
+def test_every_switch_the_library_reads_is_documented():
+    """Every DIRTORCH_AMD_* variable read_env() looks at (csrc/engine.hip) appears in the header's switch list or in
+    INTEGRATION.md - a kernel switch nobody can find is a kernel nobody can bisect."""
+    import re
+    src = open(os.path.join(ROOT, 'deep-image-retrieval_amd', 'csrc', 'engine.hip')).read()
+    body = src[src.index('static Env read_env()'):src.index('static Env g_env[2]')]
+    names = set(re.findall(r'"(DIRTORCH_AMD_[A-Z0-9_]+)"', body))
+    assert len(names) >= 25
+    docs = open(os.path.join(ROOT, 'include', 'dir_engine.h')).read() + open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = sorted(n for n in names if n not in docs and n.replace('DIRTORCH_AMD', '') not in docs)
+    assert not missing, missing
+
+
 def test_argument_errors_do_not_need_a_gpu():
     from dirtorch_amd import _lib
     lib = _lib.load()
