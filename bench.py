@@ -326,7 +326,7 @@ def other_workloads(args, x_bench):
                              'ms_per_step_spread': r['ms_per_step_spread'], 'batch': a.ms_batch,
                              'size': a.ms_size, 'step_mfma_frac': r['roofline']['frac'], 'dtype': r['dtype'],
                              **{k: v_ for k, v_ in r['config'].items() if k.startswith(('one_minus_cos', 'tolerance', 'meets_tolerance',
-                                                                                        'parity_sample', 'fp16_images_per_sec'))}}
+                                                                                        'parity_sample', 'fp16_images_per_sec', 'scale_streams'))}}
         except Exception as e:      # noqa: BLE001 - report and go on
             out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         torch.cuda.empty_cache()
@@ -620,13 +620,19 @@ def bench_multiscale(args, world, rank, dist):
     shard = torch.empty(K * B, net.out_dim, device='cuda')
 
     last = {}
+    # Round 6: the three forwards go through the host mirror's stream pool (dirtorch_amd/test_dir.py StreamPool - what
+    # extract_multiscale_features does with the scales of its images): the small scale's under-filled launches and the large one's
+    # tail rounds fill each other's idle CUs.  Same kernels on the same data: bit-identical to one stream (scripts/exp_multiscale_streams.py).
+    from dirtorch_amd.test_dir import StreamPool
+    spool = StreamPool(max(1, getattr(args, 'ms_streams', 3)))
 
     def step(n_=None):
         n_ = n_ or net
         per_scale = []
         for size in sizes:
             x = img if size == (S, S) else ops.resize_bilinear_u8(img, size)
-            per_scale.append(n_(x))
+            per_scale.append(spool.run(lambda x=x: n_(x), x))
+        spool.join()
         last['per_scale'] = per_scale
         return common.l2_normalize(common.pool(per_scale, 'gem', 3))
 
@@ -705,7 +711,7 @@ def bench_multiscale(args, world, rank, dist):
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'configs[4]: %s-GeM multi-scale (3 scales %s) extraction of %dx%d uint8 images, %s, '
                                'image-parallel, one all-gather of descriptor blocks' % (args.arch, [s_[0] for s_ in sizes], S, S, args.dtype),
-                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim), **extra,
+                   'batch_per_gpu': B, 'descriptor_dim': int(net.out_dim), 'scale_streams': len(spool.streams) or 1, **extra,
                    'rccl_ranks': dist.get_world_size() if dist is not None else 0},
         'roofline': {'bound': 'mfma', 'kernel': 'whole step (three dir_forward passes + resize + pooling)',
                      'achieved': round(ips / world * gflop / 1e3, 1), 'peak': PEAK_TFLOPS['fp16'], 'unit': 'TFLOP/s',
@@ -830,6 +836,9 @@ def main():
                     help="extract = BASELINE configs[1] (default); multiscale = configs[4] (3 scales of 1200^2, fp16); distractors = configs[3]: a database of --db-rows "
                          "2048-d descriptors sharded over the ranks, ONE all-gather, Q x N similarity, device rank + AP")
     ap.add_argument('--ms-batch', type=int, default=16, help='multiscale: images per GPU per step (8 / 16 / 24: 381 / 416 / 400 three-scale img/s)')
+    ap.add_argument('--ms-streams', type=int, default=3,
+                    help='multiscale: HIP streams the three scales\' forwards are issued on (the host mirror\'s StreamPool, what '
+                         'extract_multiscale_features does; 1 = one after the other: 427 -> 445 three-scale img/s on one box, bit-identical)')
     ap.add_argument('--ms-size', type=int, default=1200, help='multiscale: side of the (square) source images')
     ap.add_argument('--db-rows', type=int, default=1006322, help='distractors: database size (RParis6K + 1M)')
     ap.add_argument('--queries', type=int, default=70)
