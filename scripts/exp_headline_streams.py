@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The headline step (32 x 1024^2 uint8, ResNet-101 GeM, fp16p) as ONE forward of 32 images against k forwards of 32 / k images
-on k streams of the host mirror's pool: do concurrent sub-batches fill each other's kernel tails?"""
+on k streams of the host mirror's pool: do concurrent sub-batches fill each other's kernel tails?  Measured (round 6): no -
+2 462 img/s as one forward, 2 468 as 2 x 16 on two streams, 2 326 as 2 x 16 on one, 2 083-2 167 as 4 x 8."""
 import os
 import sys
 import time
