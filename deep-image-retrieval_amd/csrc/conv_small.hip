@@ -4,18 +4,22 @@
 // The reference's real regime is batch 1 at native size (dirtorch/test_dir.py:52-55): a layer3 conv of one 1024^2 image is
 // 4 096 output pixels.  The tile variants of conv_igemm.hip give such a layer 16-128 workgroups for 256 CUs, and its 64 x 64
 // variant - one tile per CU - spends a K-step (four MFMAs per wave) on a workgroup barrier, a counted wait, its share of the
-// LDS-DMA issue and a dependent MFMA chain: ~1 000 cycles per step at any ring depth (profiles/r06_small_map.txt: 19 us for
-// layer3's 3x3 where fill bytes and MFMAs alone would take ~7).  This kernel takes those four things apart:
-//   * waves 4-7 LOADERS: each issues a quarter of every stage (2 + 2 LDS-DMA instructions of 1 KB: 64 pixel rows and 64 weight
-//     rows of 128 bytes), keeps NST - 2 stages in flight behind a counted vmcnt (nothing but its own LDS-DMA is ever in its
-//     queue) and publishes "my part of stage g has landed" in an LDS word; it reuses a ring slot when the four consumers'
-//     words say they have left it.  Same gather as conv_igemm.hip (any R x S <= 4 x 4, stride, padding; K order = channel
-//     slice outermost, taps innermost; chunks of a row XOR-swizzled on the source side).
-//   * waves 0-3 CONSUMERS: a 32 x 32 sub-tile each; per stage one 16-byte poll of the loaders' words, eight fragment reads,
-//     four MFMAs alternating between TWO accumulators (no dependent chain; summed in the epilogue), one word written back.
-//     No workgroup barrier anywhere in the loop: a wave that finds its stage landed never waits for its neighbours.
+// LDS-DMA issue and a dependent MFMA chain: ~860 cycles per step at any ring depth (profiles/r06_small_map.txt: 16-19 us for
+// layer3's 3x3).  This kernel takes those four things apart:
+//   * waves 4-7 LOADERS: each issues a quarter of every stage (2 + 2 LDS-DMA instructions of 1 KB per K-step of 64: 64 pixel rows
+//     and 64 weight rows of 128 bytes), keeps LAG stages in flight behind a counted vmcnt (nothing but its own LDS-DMA is ever in
+//     its queue) and publishes "my part of stage g has landed" in an LDS word; it reuses a ring slot when the four consumers' words
+//     say they have left it (NST - LAG - 1 stages of slack between the roles).  Same gather as conv_igemm.hip (any R x S <= 4 x 4,
+//     stride, padding; K order = channel slice outermost, taps innermost; chunks of a row XOR-swizzled on the source side).
+//   * waves 0-3 CONSUMERS: a 32 x 32 sub-tile each, software-pipelined over the ring: the fragments of stage g + 1 are requested
+//     before the MFMAs of stage g are issued, the loaders' words are read only when the cached count does not cover the stage, a
+//     slot is given back as soon as its fragment reads are issued; four MFMAs per K-step alternating between TWO accumulators (no
+//     dependent chain; summed in the epilogue).  No workgroup barrier anywhere in the loop.
+//   * KPS = 1 or 2 K-steps per ring stage (16 / 32 KB: half the hand-offs for the same bytes).
 //   * one continuous ring over all the tiles of a persistent workgroup; bias, residual (both requested at the top of a tile)
 //     and ReLU in the epilogue, 16-byte stores straight from the accumulators (v_permlane32_swap, conv_ring.hip).
+// Measured (profiles/r06_small_map.txt sections 5-6): parity-green, and NOT faster than conv_igemm.hip's 64 x 64 tile with its barrier
+// per step - the regime is bounded by L2 bandwidth per FLOP, not by the hand-off.  A tuner candidate (`64x64_small_s8 / _s4 / _s4k2`).
 // Sums differ from the other variants in fp32 order (two accumulators, bias last): parity to 16-bit rounding, not bit for bit.
 // Every spin is bounded: a wave that waits ~0.5 s raises bit 1 of the overflow word and lets go (results are then garbage,
 // the host sees the flag; a lost hand-off must not hang the GPU).
@@ -76,23 +80,6 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
     if (tid < 8) cnt[tid] = 0;
     __syncthreads();   // the only workgroup barrier of the kernel
 
-    // all four words of a group >= target (bounded spin; every lane reads the same 16 bytes)
-    auto await4 = [&](const int* c, int target) {
-        for (int spins = 0;; ++spins) {
-            const int v0 = __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int v1 = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int v2 = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int v3 = __hip_atomic_load(c + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (min(min(v0, v1), min(v2, v3)) >= target) break;
-            if (spins > SPIN_LIMIT) {
-                if (a.ovf && lane == 0) atomicOr(a.ovf, 2);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-
     if (wave >= 4) {
         // ================================ loaders ======================================================================
         const int l = wave - 4;
@@ -132,7 +119,7 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs a) {
         tile_offsets(first);
         const uint32_t cnt_lds = (uint32_t)(uintptr_t)(DIR_LDS int*)cnt;
         for (int g = 0; g < total; ++g) {
-            if (g >= NST) {   // the consumers have left the slot this stage goes to (bounded spin, see await4)
+            if (g >= NST) {   // the consumers have left the slot this stage goes to (bounded spin)
                 for (int spins = 0;; ++spins) {
                     const u32x4_t c4 = lds_read4_raw(cnt_lds + 16);
                     if ((int)min(min(c4[0], c4[1]), min(c4[2], c4[3])) >= g + 1 - NST) break;

@@ -186,7 +186,9 @@ int dir_stem_pool_u8(const void* img_u8, const float* w_oihw, const float* bn_sc
  * DIR_FP16 storage saturates at 65504.  Every kernel that packs fp32 sums into fp16 for a store ORs into an
  * engine-owned device word when it stores an inf / NaN - the first overflow of a forward is always such a store,
  * so a later ReLU (hardware max drops NaN operands) or a fused consumer cannot hide it.  This call synchronises
- * `stream`, returns the word in *overflowed (0 / 1) and clears it; the word is sticky across forwards until then.
+ * `stream`, returns the word in *overflowed (0 = clean) and clears it; the word is sticky across forwards until then.
+ * Bit 0: an fp16 store overflowed.  Bit 1 (round 6): a kernel whose wave roles meet on LDS counters (conv_c3c1lc.hip, conv_small.hip)
+ * gave up a bounded wait - its results are invalid; it cannot happen on a healthy device and is reported instead of hanging it.
  * Always 0 for DIR_BF16 (fp32's exponent range).  The host mirror raises FloatingPointError naming the
  * DIRTORCH_AMD_DTYPE switch (dirtorch_amd/test_dir.py _check_finite). */
 int dir_engine_overflow(dir_engine* e, void* stream, int* overflowed);
