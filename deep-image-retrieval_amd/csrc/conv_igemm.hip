@@ -602,7 +602,10 @@ int conv_pick_variant(const ConvArgs& a) {
         // A/B at batch 32 (gpurun_out/r2b): 81 -> 71 us there, but 87 -> 90 us on layer3's 1024 -> 256 -
         // those are not short of HBM requests in flight, so they keep the 2-slot form.
         const bool no_x3 = env().no_x3;      // A/B and bisecting
-        const bool x3 = a.R * a.S == 1 && !a.res && !no_x3 && T >= 32;
+        // Round 6: the tuner's pick flipped on layer3's 1024 -> 256 conv1 (22 launches; in-place identity blocks and the loader /
+        // consumer 3x3 have changed what runs around it since round 2): 88-90 -> 82-84 us per launch, +0.9 % on the step
+        // (gpurun_out/r6tune32).  256-channel outputs take the deep-X ring from K = 1024; DIRTORCH_AMD_X3_K2048 = the old rule.
+        const bool x3 = a.R * a.S == 1 && !a.res && !no_x3 && (T >= 32 || (T >= 16 && a.Cout <= 256 && !env().x3_k2048));
         // 3x3 over 256 / 512 channels: the plane-at-a-time patch kernel (conv_patch.hip) - falls through to the
         // 16-wave implicit-GEMM tile where it is not admissible (stride 2, odd widths) or too few tiles
         const bool no_ps = env().no_patchs;  // A/B and bisecting

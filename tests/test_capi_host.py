@@ -189,7 +189,7 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     batch32 = {
         'l1.conv1': '256x64_w4x1', 'l1.conv2': '256x64_patchlc3x3', 'l1.conv3': '256x64_w4x1',
         'l2.conv1': '256x128_w4x2_s3_k32', 'l2.conv2': '512x128_patch3x3w', 'l2.conv3': '64x512_wreg1x1',
-        'l3.conv1': '256x256_persist1x1', 'l3.conv2': '512x128_patch3x3w', 'l3.conv3': '64x512_wreg1x1',
+        'l3.conv1': '256x256_persist1x1_x3', 'l3.conv2': '512x128_patch3x3w', 'l3.conv3': '64x512_wreg1x1',
         'l4.conv1': '256x256_persist1x1_x3', 'l4.conv2': '512x128_patch3x3w', 'l4.conv3': '256x256_persist1x1',
     }
     for name, s in shapes.items():
