@@ -9,7 +9,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-but-set-variable"
-SRCS="conv_f32 conv_pair conv_igemm conv_small conv_patch conv_patchlc conv_patchw conv_persist conv_persistlc conv_wreg conv_wregd conv_c3c1 conv_c3c1lc stem_pool stem_u8 pointwise resize gemm_f32 sim_split ranking comm engine c_api"
+SRCS="conv_f32 conv_pair conv_igemm conv_small conv_patch conv_patchlc conv_patchw conv_patchs2 conv_persist conv_persistlc conv_wreg conv_wregd conv_c3c1 conv_c3c1lc stem_pool stem_u8 pointwise resize gemm_f32 sim_split ranking comm engine c_api"
 if [ -n "${DIR_EXPERIMENTS:-}" ]; then
   OUT="$HERE/../dirtorch_amd/libdir_engine_exp.so"; OBJ="$HERE/_build_exp"; FLAGS="$FLAGS -DDIR_EXPERIMENTS"; SRCS="$SRCS conv_ring conv_seam3"
 else

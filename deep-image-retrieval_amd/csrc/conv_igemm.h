@@ -107,6 +107,8 @@ bool conv_patch3x3s_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3s_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3w_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3w_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+bool conv_patch3x3s2_admissible(const ConvArgs& a);   // conv_patchs2.hip: 3x3 stride 2
+hipError_t conv_patch3x3s2_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

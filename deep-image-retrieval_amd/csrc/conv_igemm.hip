@@ -492,6 +492,9 @@ static const ConvVariant kVariants[] = {
     {"256x256_patch3x3s", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 5, {nullptr, nullptr}, {nullptr, nullptr}},
     // ... 512 pixels x 128 channels per workgroup, 32-channel planes double-buffered, one filter row per weight stage
     {"512x128_patch3x3w", 512, 128, 512, 3, 32, {nullptr, nullptr}, {nullptr, nullptr}, 6, {nullptr, nullptr}, {nullptr, nullptr}},
+    // 3x3 STRIDE 2 (conv2 of the first block of layers 2-4): persistent, 8 x 32 output pixels x 128 channels from a 17 x 65 patch,
+    // 32-channel planes double-buffered with even / odd input columns apart, weights straight into registers (conv_patchs2.hip)
+    {"256x128_patchs2", 256, 128, 768, 2, 32, {nullptr, nullptr}, {nullptr, nullptr}, 12, {nullptr, nullptr}, {nullptr, nullptr}},
     // persistent workgroups, next tile's first K-stage issued before the epilogue (conv_persist.hip)
     {"256x256_persist1x1", 256, 256, 512, 2, 64, {nullptr, nullptr}, {nullptr, nullptr}, 2, {nullptr, nullptr}, {nullptr, nullptr}},
     // the same with three K-steps of the pixel operand in the ring (HBM requests in flight: 32 -> 64+ KB per CU)
@@ -536,6 +539,7 @@ bool conv_variant_admissible(int v, const ConvArgs& a) {
     if (cv.kind == 7) return conv1x1_ring_admissible(a);
 #endif
     if (cv.kind == 8) return conv_patch64_lc_admissible(a);
+    if (cv.kind == 12) return conv_patch3x3s2_admissible(a);
     if (cv.kind == 11) return conv_small_admissible(a) && (cv.stages != 5 || (a.Ktot / 64) % 2 == 0);
     if (cv.kind == 10) return a.x2 == nullptr && conv1x1_lc_admissible(a);
     if (cv.kind == 9) return conv1x1_wregd_admissible(a);   // (two-source shapes only: never true for a plain conv)
@@ -569,6 +573,14 @@ int conv_pick_variant(const ConvArgs& a) {
         const int v = find_variant("256x64_patchlc3x3");
         if (!no_lc && v >= 0 && conv_variant_admissible(v, a) &&
             (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) >= 192)
+            return v;
+    }
+    {
+        // 3x3 stride 2 (the first conv2 of layers 2-4): the patch kernel with even / odd column runs (DIRTORCH_AMD_NO_PATCHS2:
+        // the generic strided tiles again), as long as three quarters of the CUs get a tile
+        const int v = find_variant("256x128_patchs2");
+        if (!env().no_patchs2 && v >= 0 && conv_variant_admissible(v, a) &&
+            (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) * (a.Cout / 128) >= 192)
             return v;
     }
     for (int v = 0; v < kNumVariants; ++v)
@@ -806,6 +818,7 @@ int conv_launch(const ConvArgs& a, int dtype, int variant, hipStream_t stream) {
                    : cv.kind == 7 ? conv1x1_ring_launch(a, dtype, stream)
 #endif
                    : cv.kind == 8 ? conv_patch64_lc_launch(a, dtype, stream)
+                   : cv.kind == 12 ? conv_patch3x3s2_launch(a, dtype, stream)
                    : cv.kind == 10 ? conv1x1_lc_launch(a, dtype, stream)
                    : cv.kind == 11 ? conv_small_launch(a, dtype, cv.stages, stream)
                    : a.ksplit > 1 ? cv.launch_sk[dtype](a, stream)

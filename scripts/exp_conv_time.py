@@ -19,6 +19,8 @@ SHAPES = {   # name: (B, H, W, Cin, Cout, k, stride, pad, residual)
     'l4.conv2': (32, 32, 32, 512, 512, 3, 1, 1, False),
     'l4.conv1': (32, 32, 32, 2048, 512, 1, 1, 0, False),
     'l3.0.conv1': (32, 128, 128, 512, 256, 1, 1, 0, False),
+    'l2.0.conv2': (32, 256, 256, 128, 128, 3, 2, 1, False), 'l3.0.conv2': (32, 128, 128, 256, 256, 3, 2, 1, False),
+    'l4.0.conv2': (32, 64, 64, 512, 512, 3, 2, 1, False),   # the strided 3x3 convs of the first blocks (round 6: conv_patchs2.hip)
 }
 names = []
 n = _lib.load().dir_conv_variant_count()

@@ -84,6 +84,9 @@ def short(name):
     if m:   # <DT, XDEEP, RES[, DUAL]>
         return 'conv_igemm<256x256_persist1x1%s%s>[%s]' % ('_x3' if m.group(2) == 'true' else '',
                                                            '/dual' if m.group(4) == 'true' else '', m.group(1).lower())
+    m = re.search(r'conv_patch3x3s2_kernel<dir::(\w+)>', name)   # the stride-2 patch kernel (csrc/conv_patchs2.hip, round 6)
+    if m:
+        return 'conv_igemm<256x128_patchs2>[%s]' % m.group(1).lower()
     m = re.search(r'conv_patch3x3s_kernel<dir::(\w+), (\d+)>', name)
     if m:
         return 'conv_igemm<256x256_patch3x3s>[%s]' % m.group(1).lower()

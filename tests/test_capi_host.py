@@ -205,7 +205,9 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     assert pick(8, *shapes['l3.conv2']) == ('128x128_w2x2', 1)
     # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
     # the strided 3x3 of layer2.0 (256^2 -> 128^2): the BK = 64 tile
-    assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_w4x2_s3', 1)
+    assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_patchs2', 1)      # (round 6: the strided patch kernel)
+    assert pick(32, 128, 256, 256, 3, 2, 0) == ('256x128_patchs2', 1) and pick(32, 64, 512, 512, 3, 2, 0) == ('256x128_patchs2', 1)
+    assert pick(1, 256, 128, 128, 3, 2, 0)[0] != '256x128_patchs2'           # 64 tiles: too few for the persistent kernel
     assert pick(32, 64, 256, 1024, 1, 1, 0)[0] != '64x512_wreg1x1'
     assert pick(2, 64, 256, 1024, 1, 1, 1)[0] != '64x512_wreg1x1'
 

@@ -19,7 +19,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'deep-image-retrieval_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-RING_SOURCES = ['conv_igemm', 'conv_pair', 'conv_patch', 'conv_patchlc', 'conv_patchw', 'conv_persist', 'conv_persistlc', 'conv_ring', 'conv_seam3', 'conv_wreg', 'conv_wregd', 'conv_c3c1lc',
+RING_SOURCES = ['conv_igemm', 'conv_pair', 'conv_patch', 'conv_patchlc', 'conv_patchw', 'conv_patchs2', 'conv_persist', 'conv_persistlc', 'conv_ring', 'conv_seam3', 'conv_wreg', 'conv_wregd', 'conv_c3c1lc',
                 'sim_split', 'stem_pool', 'stem_u8']
 RING_KERNELS = re.compile(r'conv_igemm_kernel|conv_patch3x3\w*_kernel|conv_patch64_lc_kernel|conv1x1_persist_kernel|conv1x1_ring_kernel|'
                           r'conv1x1_wreg_kernel|conv1x1_lc_kernel|conv1x1_wregd_kernel|conv_c3c1ds_lc_kernel|sim_split\w*_kernel|whiten_split_kernel|stem_pool_persist_kernel|conv_pair_kernel|conv_pair_patch64_kernel|conv_seam3_kernel|stem_pool_pair_persist_kernel|stem_pool_u8_kernel')

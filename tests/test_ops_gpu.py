@@ -44,6 +44,8 @@ def variant_admissible(name, Cin, Cout, k, stride, pad, has_res=True):
         return False
     if 'wreg1x1' in name:
         return k == 1 and stride == 1 and pad == 0 and Cout % 512 == 0 and Cin in (128, 256) and has_res
+    if 'patchs2' in name:                # 3x3 stride 2 from a 17 x 65 patch with even / odd column runs (conv_patchs2.hip)
+        return k == 3 and stride == 2 and pad == 1 and Cin % 64 == 0 and Cout % 128 == 0 and not has_res
     if 'patchlc3x3' in name:             # filter resident in LDS, loader / consumer waves: 64 -> 64 without a residual
         return k == 3 and stride == 1 and pad == 1 and Cin == Cout == 64 and not has_res
     if 'patch3x3w' in name:              # 512 pixels x 128 channels per workgroup, 32-channel planes
@@ -105,6 +107,10 @@ CONV_SHAPES = [
     ('3x3_s1_c128', 1, 17, 18, 128, 128, 3, 1, 1, False, True),
     ('3x3_s2', 2, 15, 14, 128, 128, 3, 2, 1, False, True),
     ('1x1_s2_ds', 2, 14, 13, 256, 512, 1, 2, 0, False, False),
+    ('3x3_s2_exact_tile', 1, 16, 64, 64, 128, 3, 2, 1, False, False),     # one 8 x 32 output tile, two planes, no ReLU
+    ('3x3_s2_ragged_c256', 2, 37, 70, 256, 256, 3, 2, 1, False, True),    # 19 x 35 outputs: 3 x 2 ragged tiles x 2 channel tiles per image
+    ('3x3_s2_odd_c512', 1, 17, 33, 512, 512, 3, 2, 1, False, True),       # odd input sizes (9 x 17 outputs), 16 planes, four channel tiles
+    ('3x3_s2_persistent', 9, 128, 128, 64, 256, 3, 2, 1, False, True),    # 288 tiles: more than one per workgroup, the channel tile changes between them
     ('3x3_multi_tile', 4, 20, 20, 64, 128, 3, 1, 1, True, True),
     ('3x3_patch64_ragged', 2, 13, 37, 64, 64, 3, 1, 1, True, True),
     ('3x3_patch64_ragged_nores', 3, 21, 45, 64, 64, 3, 1, 1, False, True),   # 3 x 2 tiles per image, ragged both ways, 18 tiles
