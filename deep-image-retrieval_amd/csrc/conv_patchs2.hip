@@ -14,7 +14,10 @@
 //     by the slot's index in its row, (c >> 2) & 3), where the natural layout would put every lane pair on the same banks;
 //   * weights never touch LDS: a consumer wave owns 32 output channels x 4 output rows, and loads its weight fragments
 //     (one filter row of one plane: 6 x 16 bytes per lane) from L2 straight into registers one filter row ahead of the
-//     MFMAs that use them (the two waves of a channel tile share a SIMD and the L1 lines);
+//     MFMAs that use them - from a FRAGMENT-ORDERED copy of the filter (pack_patchs2_kernel: the engine keeps one per
+//     strided layer since finalize(), the per-op entry point packs into stream-ordered scratch), so that a wave-level load
+//     is one contiguous KB.  (First build, from the [Cout][3][3][Cin] layout: 32 segments of 32 bytes per instruction,
+//     ~260 cycles each in the CU's texture path - 0.6 ms per launch, 18 us per plane whatever the layer.)
 //   * outputs leave straight from the accumulators (ReLU, pack, v_permlane32_swap -> one 16-byte store per lane).
 // Twelve waves: 0-7 multiply (wave = channel tile w & 3, row half w >> 2; 72 MFMAs per plane, 64 accumulator registers),
 // 8-11 only issue LDS-DMA (18 x 1 KB pieces per plane each) and wait for it; ONE workgroup barrier per plane is the
@@ -114,16 +117,16 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
 
     // ==================================== consumers ================================================================================
     const int ct = wave & 3, rh = wave >> 2;
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
-    const uint32_t wvoff = (uint32_t)((((ct * 32 + lrow) * 9) * a.Cin + lhi * 8) * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_s2, 0, a.w_bytes, 0x00020000);
+    const uint32_t wvoff = (uint32_t)(lane * 16);
     frag_t W[2][3][2];   // two sets (this filter row / the next one) x tap x K half
     auto load_w = [&](frag_t (&w)[3][2], int tile_n, int q, int r) __attribute__((always_inline)) {
+        const int blk = ((((tile_n * NQ + q) * 3 + r) * 4 + ct) * 6) * 1024;   // pack_patchs2_kernel's order
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
-                w[s][kk] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          rsrc_w, wvoff, ((tile_n * BN * 9 + r * 3 + s) * a.Cin + q * 32 + kk * 16) * 2, 0));
+                w[s][kk] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff, blk + (s * 2 + kk) * 1024, 0));
     };
     // fragment of output row j (of this wave's four), filter row r, tap s: slot (2 (4 rh + j) + r) * 65 + c, c = {0, 33, 1}[s] + lrow;
     // its 16-byte chunks are swizzled by the slot's index IN ITS ROW, (c >> 2) & 3, so that a lane has one address per (tap, K half)
@@ -230,6 +233,36 @@ bool conv_patch3x3s2_admissible(const ConvArgs& a) {
            (size_t)a.B * a.H * a.W * a.Cin * 2 < (1ull << 31) && (size_t)a.Cout * a.Ktot * 2 < (1ull << 31);
 }
 
+// The filter in the order the consumers read it: 16-byte piece ((((tile_n * NQ + q) * 3 + r) * 4 + ct) * 6 + s * 2 + kk) * 64 + lane
+// = w[tile_n * 128 + ct * 32 + (lane & 31)][r][s][q * 32 + kk * 16 + (lane >> 5) * 8 .. + 8]  (same bytes, same size).
+__global__ void __launch_bounds__(256) pack_patchs2_kernel(const uint16_t* w, uint16_t* out, int Cout, int Cin) {
+    const int NQ = Cin / 32;
+    const long pieces = (long)Cout * 9 * Cin / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
+        long t = i;
+        const int lane = (int)(t & 63);
+        t >>= 6;
+        const int sk = (int)(t % 6);
+        t /= 6;
+        const int ct = (int)(t & 3);
+        t >>= 2;
+        const int r = (int)(t % 3);
+        t /= 3;
+        const int q = (int)(t % NQ);
+        const int tn = (int)(t / NQ);
+        const int s = sk >> 1, kk = sk & 1;
+        const size_t src = ((size_t)((tn * 128 + ct * 32 + (lane & 31)) * 9 + r * 3 + s)) * Cin + q * 32 + kk * 16 + (lane >> 5) * 8;
+        gstore16(out + i * 8, gload16(w + src));
+    }
+}
+
+hipError_t conv_patch3x3s2_pack(const uint16_t* w, uint16_t* out, int Cout, int Cin, hipStream_t stream) {
+    const long pieces = (long)Cout * 9 * Cin / 8;
+    const int grid = (int)((pieces + 255) / 256 < 1024 ? (pieces + 255) / 256 : 1024);
+    hipLaunchKernelGGL(pack_patchs2_kernel, dim3(grid), dim3(256), 0, stream, w, out, Cout, Cin);
+    return hipGetLastError();
+}
+
 template <class DT>
 static hipError_t launch_patch_s2(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * 70 * 1024;
@@ -239,11 +272,25 @@ static hipError_t launch_patch_s2(const ConvArgs& a, hipStream_t stream) {
     ConvArgs b = a;
     b.x_bytes = (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 2);
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
+    void* scratch = nullptr;
+    if (!b.w_s2) {   // the per-op entry point (dir_conv_bn_act): no packed copy kept anywhere - stream-ordered scratch for this launch
+        if (hipError_t e = hipMallocAsync(&scratch, b.w_bytes, stream); e != hipSuccess) return e;
+        if (hipError_t e = conv_patch3x3s2_pack(a.w, (uint16_t*)scratch, a.Cout, a.Cin, stream); e != hipSuccess) {
+            (void)hipFreeAsync(scratch, stream);
+            return e;
+        }
+        b.w_s2 = (const uint16_t*)scratch;
+    }
     const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) * (a.Cout / 128);
     const int ncu = cu_count();
     const int grid = tiles < ncu ? (int)tiles : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(768), LDS, stream, b);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (scratch) {
+        const hipError_t f = hipFreeAsync(scratch, stream);
+        if (e == hipSuccess) e = f;
+    }
+    return e;
 }
 
 hipError_t conv_patch3x3s2_launch(const ConvArgs& a, int dtype, hipStream_t stream) {

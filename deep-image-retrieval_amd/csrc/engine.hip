@@ -296,6 +296,11 @@ int dir_engine::finalize(int dt) {
         }
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed16.size() * 2));
         DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
+        if (!L.stem && L.R == 3 && L.S == 3 && L.stride == 2 && L.pad == 1 && L.Cin % 64 == 0 && L.Cout % 128 == 0) {
+            // conv2 of a stage's first block: conv_patchs2.hip reads its weight fragments as contiguous KBs from this copy
+            DIR_HIP_CHECK(hipMalloc((void**)&L.d_w_s2, packed16.size() * 2));
+            DIR_HIP_CHECK(conv_patch3x3s2_pack(L.d_w, L.d_w_s2, L.Cout, L.Cin, nullptr));
+        }
         if (L.stem && dt == DIR_FP16P) {   // (after the range check above: a weight the plain form refuses is reported as that layer's)
             const int rc = fold_stem_u8(L, w->data.data(), scale.data(), bias.data());
             if (rc != DIR_OK) return rc;
@@ -422,6 +427,8 @@ void dir_engine::release() {
         L.d_wf = nullptr;
         if (L.d_w_lo) (void)hipFree(L.d_w_lo);
         L.d_w_lo = nullptr;
+        if (L.d_w_s2) (void)hipFree(L.d_w_s2);
+        L.d_w_s2 = nullptr;
         if (L.d_bias) (void)hipFree(L.d_bias);
         if (L.d_w_ds) (void)hipFree(L.d_w_ds);
         if (L.d_w_ds_lo) (void)hipFree(L.d_w_ds_lo);
@@ -568,6 +575,7 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
     a.rev_m = rev_m ? 1 : 0;
     a.x = x;
     a.w = L.d_w;
+    a.w_s2 = L.d_w_s2;
     a.bias = L.d_bias;
     a.res = res;
     a.y = y;
