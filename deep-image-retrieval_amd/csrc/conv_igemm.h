@@ -40,6 +40,7 @@ struct ConvArgs {
     const uint16_t* x_lo;
     const uint16_t* x2_lo;   // ... and of the second K source (x2) in the two-source form
     const uint16_t* w_lo;
+    const uint16_t* w_pw;    // conv_patchw.hip (loader / consumer form): w as its LDS stage images (conv_patch3x3w_pack), or null (gathered from w)
     const uint16_t* w_s2;    // conv_patchs2.hip: w in fragment order (conv_patch3x3s2_pack), or null (the launcher packs into scratch)
     const uint16_t* w2_lo;   // the fused seam (conv_c3c1.hip, WP1): lo plane of the following conv1's weights
     const uint16_t* res_lo;
@@ -108,6 +109,7 @@ bool conv_patch3x3s_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3s_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 bool conv_patch3x3w_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3w_launch(const ConvArgs& a, int dtype, hipStream_t stream);
+hipError_t conv_patch3x3w_pack(const uint16_t* w, uint16_t* out, int Cout, int Cin, hipStream_t stream);   // same size as w
 bool conv_patch3x3s2_admissible(const ConvArgs& a);   // conv_patchs2.hip: 3x3 stride 2
 hipError_t conv_patch3x3s2_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 hipError_t conv_patch3x3s2_pack(const uint16_t* w, uint16_t* out, int Cout, int Cin, hipStream_t stream);   // same size as w

@@ -17,6 +17,8 @@
 // 16-byte chunks swizzled by (row >> 2) & 3), fp32 staging for coalesced 16-byte stores.
 #include "dir_common.h"
 #include "conv_igemm.h"
+#include <map>
+#include <mutex>
 
 // Timing-only experiment builds (scripts/exp_abl.sh conv_patchw DIR_PATCHW_ABL <bits>): 1 = no global stores in the epilogue
 // (staging kept), 2 = no epilogue at all (one never-taken store keeps the accumulators alive), 4 = no prologue wait: the first
@@ -326,7 +328,6 @@ __global__ void __launch_bounds__(768) conv_patch3x3w_lc_kernel(const ConvArgs a
         const int lt = tid - 512;              // 0 .. 255
         const int lw = wave - 8;
         const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
         uint32_t pvoff[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -337,12 +338,16 @@ __global__ void __launch_bounds__(768) conv_patch3x3w_lc_kernel(const ConvArgs a
             const bool ok = p < PP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             pvoff[i] = ok ? (uint32_t)((((b * a.H + iy) * a.W + ix) * a.Cin + ((pos ^ ((p >> 2) & 3)) << 3)) * 2) : kOOBw;
         }
+        // a.w_pw (conv_patch3x3w_pack): the filter as the sequence of 24 KB LDS stage images - a DMA instruction copies one
+        // contiguous KB instead of gathering sixteen 64-byte runs of the [Cout][3][3][Cin] layout
+        const bool packed = a.w_pw != nullptr;
+        const __amdgpu_buffer_rsrc_t rsrc_wp = __builtin_amdgcn_make_buffer_rsrc((void*)(packed ? a.w_pw : a.w), 0, a.w_bytes, 0x00020000);
         uint32_t wvoff[NBW];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int L = i * NLD + lt;
             const int s = L >> 9, n = (L & 511) >> 2, pos = L & 3;
-            wvoff[i] = (uint32_t)((((tile_n * BN + n) * 9 + s) * a.Cin + ((pos ^ ((n >> 2) & 3)) << 3)) * 2);
+            wvoff[i] = packed ? (uint32_t)(L * 16) : (uint32_t)((((tile_n * BN + n) * 9 + s) * a.Cin + ((pos ^ ((n >> 2) & 3)) << 3)) * 2);
         }
         auto issue_plane = [&](int q) {
             char* dst = smem + (q & 1) * PLANE_BYTES;
@@ -352,8 +357,9 @@ __global__ void __launch_bounds__(768) conv_patch3x3w_lc_kernel(const ConvArgs a
         auto issue_w = [&](int sigma, int slot) {
             const int q = sigma / 3, r = sigma - q * 3;
             char* dst = smem + WOFF + slot * WSTAGE;
+            const int soff = packed ? (tile_n * NS + sigma) * WSTAGE : (r * 3 * a.Cin + q * 32) * 2;
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) dma16w(rsrc_w, dst + (i * NLD + lw * 64) * 16, wvoff[i], (r * 3 * a.Cin + q * 32) * 2);
+            for (int i = 0; i < NBW; ++i) dma16w(rsrc_wp, dst + (i * NLD + lw * 64) * 16, wvoff[i], soff);
         };
         // prologue: plane 0, weight stages 0 and 1 - in this order (the counted waits below rely on it)
         issue_plane(0);
@@ -508,6 +514,31 @@ bool conv_patch3x3w_admissible(const ConvArgs& a) {
            (size_t)a.Cout * a.Ktot * 2 < (1ull << 31);
 }
 
+// The filter as conv_patch3x3w_lc_kernel's LDS stage images: 16-byte piece ((tile_n * NQ + q) * 3 + r) * 1536 + L, L = (s * 128 + n) * 4 + pos,
+// = w[tile_n * 128 + n][r][s][q * 32 + (pos ^ ((n >> 2) & 3)) * 8 .. + 8]  (same bytes, same size).
+__global__ void __launch_bounds__(256) pack_patchw_kernel(const uint16_t* w, uint16_t* out, int Cout, int Cin) {
+    const int NQ = Cin / 32;
+    const long pieces = (long)Cout * 9 * Cin / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
+        const int L = (int)(i % 1536);
+        long t = i / 1536;
+        const int r = (int)(t % 3);
+        t /= 3;
+        const int q = (int)(t % NQ);
+        const int tn = (int)(t / NQ);
+        const int s = L >> 9, n = (L & 511) >> 2, pos = L & 3;
+        const size_t src = ((size_t)((tn * 128 + n) * 9 + r * 3 + s)) * Cin + q * 32 + ((pos ^ ((n >> 2) & 3)) << 3);
+        gstore16(out + i * 8, gload16(w + src));
+    }
+}
+
+hipError_t conv_patch3x3w_pack(const uint16_t* w, uint16_t* out, int Cout, int Cin, hipStream_t stream) {
+    const long pieces = (long)Cout * 9 * Cin / 8;
+    const int grid = (int)((pieces + 255) / 256 < 1024 ? (pieces + 255) / 256 : 1024);
+    hipLaunchKernelGGL(pack_patchw_kernel, dim3(grid), dim3(256), 0, stream, w, out, Cout, Cin);
+    return hipGetLastError();
+}
+
 template <class DT>
 static hipError_t launch_patch_w(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * 5 * 512 * 16 + 3 * 3 * 128 * 64;   // two planes + three weight stages = 152 KiB
@@ -517,6 +548,17 @@ static hipError_t launch_patch_w(const ConvArgs& a, hipStream_t stream) {
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     const long blocks = (long)a.B * ((a.OH + 15) / 16) * ((a.OW + 31) / 32) * (a.Cout / 128);
     if (!env().no_patchw_lc) {   // the loader / consumer form (twelve waves); DIRTORCH_AMD_NO_PATCHW_LC = the one-role kernel
+        if (!b.w_pw && env().patchw_pack) {   // (experiment: DIRTORCH_AMD_PATCHW_PACK - a packed copy per weight pointer, kept)
+            static std::mutex mu;
+            static std::map<const void*, void*> cache;
+            std::lock_guard<std::mutex> lk(mu);
+            void*& p = cache[a.w];
+            if (!p) {
+                if (hipError_t e = hipMalloc(&p, b.w_bytes); e != hipSuccess) return e;
+                if (hipError_t e = conv_patch3x3w_pack(a.w, (uint16_t*)p, a.Cout, a.Cin, stream); e != hipSuccess) return e;
+            }
+            b.w_pw = (const uint16_t*)p;
+        }
         auto kern = conv_patch3x3w_lc_kernel<DT>;
         static std::atomic<uint64_t> attr_lc{0};
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_lc); e != hipSuccess) return e;
