@@ -46,6 +46,7 @@ static Env read_env() {
     e.x3_k2048 = on("DIRTORCH_AMD_X3_K2048");
     e.no_patchs2 = on("DIRTORCH_AMD_NO_PATCHS2");
     e.patchw_pack = on("DIRTORCH_AMD_PATCHW_PACK");
+    e.persist_pack = on("DIRTORCH_AMD_PERSIST_PACK");
     e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");
     e.no_x3 = on("DIRTORCH_AMD_NO_X3");
     e.no_patchs = on("DIRTORCH_AMD_NO_PATCHS");

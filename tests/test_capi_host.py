@@ -254,7 +254,7 @@ def test_profile_tooling_knows_every_engine_kernel():
     other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_sort_kernel', 'rank_hist_kernel', 'rank_finalize_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
              'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'sim_split_lc_kernel', 'split_queries_kernel', 'whiten_split_kernel', 'fill_noise_kernel',
              'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel',
-             'pack_patchs2_kernel', 'pack_patchw_kernel'}   # (filter re-ordering at finalize / in the per-op entry points)
+             'pack_patchs2_kernel', 'pack_patchw_kernel', 'pack_persist_kernel'}   # (filter re-ordering at finalize / in the per-op entry points)
     for n in names:
         k = S.bench_kernel_name(S.short(n))
         if 'conv' in n and 'finalize' not in n and 'naive' not in n:
