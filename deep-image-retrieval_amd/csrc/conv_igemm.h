@@ -40,7 +40,6 @@ struct ConvArgs {
     const uint16_t* x_lo;
     const uint16_t* x2_lo;   // ... and of the second K source (x2) in the two-source form
     const uint16_t* w_lo;
-    const uint16_t* w_pk;    // conv_persist.hip: w as its 32 KB LDS stage images (conv1x1_persist_pack), or null (gathered from w)
     const uint16_t* w_pw;    // conv_patchw.hip (loader / consumer form): w as its LDS stage images (conv_patch3x3w_pack), or null (gathered from w)
     const uint16_t* w_s2;    // conv_patchs2.hip: w in fragment order (conv_patch3x3s2_pack), or null (the launcher packs into scratch)
     const uint16_t* w2_lo;   // the fused seam (conv_c3c1.hip, WP1): lo plane of the following conv1's weights

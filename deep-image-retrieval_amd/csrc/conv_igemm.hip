@@ -576,10 +576,12 @@ int conv_pick_variant(const ConvArgs& a) {
             return v;
     }
     {
-        // 3x3 stride 2 (the first conv2 of layers 2-4): the patch kernel with even / odd column runs (DIRTORCH_AMD_NO_PATCHS2:
-        // the generic strided tiles again), as long as three quarters of the CUs get a tile
+        // 3x3 stride 2 over 128 channels (layer2.0's conv2, bound by its full-resolution input): the patch kernel with even / odd
+        // column runs - 0.222 -> 0.208 ms standalone at batch 32 (gpurun_out/r6s2b).  Not for the 256 / 512-channel ones of
+        // layer3.0 / 4.0: those are matrix-bound, and one plane in flight per CU costs them 15-25 us against the 16-wave tile (0.174
+        // vs 0.149, 0.152 vs 0.135 ms) - the variant stays a tuner candidate there.  DIRTORCH_AMD_NO_PATCHS2: generic tiles again.
         const int v = find_variant("256x128_patchs2");
-        if (!env().no_patchs2 && v >= 0 && conv_variant_admissible(v, a) &&
+        if (!env().no_patchs2 && v >= 0 && a.Cin <= 128 && conv_variant_admissible(v, a) &&
             (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) * (a.Cout / 128) >= 192)
             return v;
     }

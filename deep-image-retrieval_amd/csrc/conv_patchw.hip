@@ -17,8 +17,6 @@
 // 16-byte chunks swizzled by (row >> 2) & 3), fp32 staging for coalesced 16-byte stores.
 #include "dir_common.h"
 #include "conv_igemm.h"
-#include <map>
-#include <mutex>
 
 // Timing-only experiment builds (scripts/exp_abl.sh conv_patchw DIR_PATCHW_ABL <bits>): 1 = no global stores in the epilogue
 // (staging kept), 2 = no epilogue at all (one never-taken store keeps the accumulators alive), 4 = no prologue wait: the first
@@ -548,22 +546,25 @@ static hipError_t launch_patch_w(const ConvArgs& a, hipStream_t stream) {
     b.w_bytes = (uint32_t)((size_t)a.Cout * a.Ktot * 2);
     const long blocks = (long)a.B * ((a.OH + 15) / 16) * ((a.OW + 31) / 32) * (a.Cout / 128);
     if (!env().no_patchw_lc) {   // the loader / consumer form (twelve waves); DIRTORCH_AMD_NO_PATCHW_LC = the one-role kernel
-        if (!b.w_pw && env().patchw_pack) {   // (experiment: DIRTORCH_AMD_PATCHW_PACK - a packed copy per weight pointer, kept)
-            static std::mutex mu;
-            static std::map<const void*, void*> cache;
-            std::lock_guard<std::mutex> lk(mu);
-            void*& p = cache[a.w];
-            if (!p) {
-                if (hipError_t e = hipMalloc(&p, b.w_bytes); e != hipSuccess) return e;
-                if (hipError_t e = conv_patch3x3w_pack(a.w, (uint16_t*)p, a.Cout, a.Cin, stream); e != hipSuccess) return e;
+        void* scratch = nullptr;
+        if (!b.w_pw && env().patchw_pack) {   // DIRTORCH_AMD_PATCHW_PACK: a per-op launch (no packed copy kept anywhere) packs into stream-ordered scratch
+            if (hipError_t e = hipMallocAsync(&scratch, b.w_bytes, stream); e != hipSuccess) return e;
+            if (hipError_t e = conv_patch3x3w_pack(a.w, (uint16_t*)scratch, a.Cout, a.Cin, stream); e != hipSuccess) {
+                (void)hipFreeAsync(scratch, stream);
+                return e;
             }
-            b.w_pw = (const uint16_t*)p;
+            b.w_pw = (const uint16_t*)scratch;
         }
         auto kern = conv_patch3x3w_lc_kernel<DT>;
         static std::atomic<uint64_t> attr_lc{0};
         if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_lc); e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), LDS, stream, b);
-        return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (scratch) {
+            const hipError_t f = hipFreeAsync(scratch, stream);
+            if (e == hipSuccess) e = f;
+        }
+        return e;
     }
     auto kern = conv_patch3x3w_kernel<DT>;
     static std::atomic<uint64_t> attr_done{0};

@@ -15,8 +15,6 @@
 // 32 pixel rows x (64 fp32 + pad), one 64-channel half of a wave's 128 channels at a time.
 #include "dir_common.h"
 #include "conv_igemm.h"
-#include <map>
-#include <mutex>
 
 namespace dir {
 
@@ -67,11 +65,8 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
 
     const __amdgpu_buffer_rsrc_t rsrc_x =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-    // a.w_pk (conv1x1_persist_pack): the weights as the sequence of 32 KB LDS stage images - contiguous KBs per DMA instruction
-    const bool wpacked = a.w_pk != nullptr;
     const __amdgpu_buffer_rsrc_t rsrc_w =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(wpacked ? a.w_pk : a.w), 0, a.w_bytes, 0x00020000);
-    int wtile = 0;
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x2 =
         __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : a.x_bytes, 0x00020000);
 
@@ -116,8 +111,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            wvoff[i] = wpacked ? (uint32_t)((i * NT + tid) * 16) : (uint32_t)(((tile_n * BN + i * 64 + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
-        wtile = wpacked ? tile_n * T * (BN * 128) : 0;
+            wvoff[i] = (uint32_t)(((tile_n * BN + i * 64 + (tid >> 3)) * a.Ktot + srcchunk * 8) * 2);
     };
     auto issue_x = [&](int t, char* dst) {
         if (DUAL && t >= T1) {
@@ -135,7 +129,7 @@ __global__ void __launch_bounds__(512) conv1x1_persist_kernel(const ConvArgs a) 
     };
     auto issue_w = [&](int t, char* dst) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) dma16q(rsrc_w, dst + (i * NT + wave * 64) * 16, wvoff[i], wtile + t * (wpacked ? BN * 128 : 128));
+        for (int i = 0; i < NB; ++i) dma16q(rsrc_w, dst + (i * NT + wave * 64) * 16, wvoff[i], t * 128);
     };
     auto issue = [&](int t, char* stage) {
         issue_x(t, stage);
@@ -355,27 +349,6 @@ bool conv1x1_persist_admissible(const ConvArgs& a) {
     return a.R == 1 && a.S == 1 && a.pad == 0 && a.Cout % 256 == 0 && a.Cin % 64 == 0 && a.Cin >= 128;
 }
 
-// The weights as the kernel's LDS stage images: 16-byte piece ((tile_n * T + t) * 2048 + L), L = i * 512 + tid,
-// = w[tile_n * 256 + i * 64 + (tid >> 3)][t * 64 + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 .. + 8]  (same bytes, same size).
-__global__ void __launch_bounds__(256) pack_persist_kernel(const uint16_t* w, uint16_t* out, int Cout, int Ktot) {
-    const int T = Ktot / 64;
-    const long pieces = (long)Cout * Ktot / 8;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
-        const int L = (int)(i & 2047);
-        const long tt = i >> 11;
-        const int t = (int)(tt % T), tn = (int)(tt / T);
-        const int tid = L & 511, row = (L >> 9) * 64 + (tid >> 3), chunk = (tid & 7) ^ ((tid >> 4) & 7);
-        gstore16(out + i * 8, gload16(w + (size_t)(tn * 256 + row) * Ktot + t * 64 + chunk * 8));
-    }
-}
-
-hipError_t conv1x1_persist_pack(const uint16_t* w, uint16_t* out, int Cout, int Ktot, hipStream_t stream) {
-    const long pieces = (long)Cout * Ktot / 8;
-    const int grid = (int)((pieces + 255) / 256 < 1024 ? (pieces + 255) / 256 : 1024);
-    hipLaunchKernelGGL(pack_persist_kernel, dim3(grid), dim3(256), 0, stream, w, out, Cout, Ktot);
-    return hipGetLastError();
-}
-
 template <class DT, bool XDEEP, bool DUAL = false>
 static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     // 2-slot map: slot 0 + staging (covers slot 1); deep-X map: 3 X slots + 2 W slots = all 160 KiB
@@ -405,17 +378,6 @@ static hipError_t launch_persist(const ConvArgs& a, hipStream_t stream) {
     };
     fd((uint32_t)(a.OH * a.OW), b.div_ohw_mul, b.div_ohw_shr);
     fd((uint32_t)a.OW, b.div_ow_mul, b.div_ow_shr);
-    if (!b.w_pk && env().persist_pack) {   // (experiment: DIRTORCH_AMD_PERSIST_PACK - a packed copy per weight pointer, kept)
-        static std::mutex mu;
-        static std::map<const void*, void*> cache;
-        std::lock_guard<std::mutex> lk(mu);
-        void*& p = cache[a.w];
-        if (!p) {
-            if (hipError_t e = hipMalloc(&p, b.w_bytes); e != hipSuccess) return e;
-            if (hipError_t e = conv1x1_persist_pack(a.w, (uint16_t*)p, a.Cout, a.Ktot, stream); e != hipSuccess) return e;
-        }
-        b.w_pk = (const uint16_t*)p;
-    }
     const int ntiles = b.tiles_m * b.tiles_n;
     const int ncu = cu_count();
     const int grid = ntiles < ncu ? ntiles : ncu;

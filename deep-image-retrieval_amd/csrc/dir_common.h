@@ -47,8 +47,7 @@ struct Env {
     bool rev_conv1 = false, rev_conv3 = false;   // ..._REV_CONV1 / _REV_CONV3: reversed tile order (measured, no gain)
     bool unfused_stem = false, stem_v1 = false;  // ..._UNFUSED_STEM, ..._STEM_V1: conv + maxpool apart / one tile per workgroup
     bool no_patchlc = false, no_wreg = false, no_patchw = false, no_x3 = false, no_patchs = false;   // heuristic: skip a kernel
-    bool persist_pack = false;                   // ..._PERSIST_PACK (experiment): conv_persist.hip's launches pack the weights into stage images once per weight pointer
-    bool patchw_pack = false;                    // ..._PATCHW_PACK (experiment): conv_patchw.hip's per-op launches pack the filter into its stage images once per weight pointer
+    bool patchw_pack = false, no_patchw_pack = false;   // ..._PATCHW_PACK: per-op conv_patchw.hip launches pack the filter into stage images (stream-ordered scratch); ..._NO_PATCHW_PACK: the engine's launches gather from the [Cout][3][3][Cin] layout again
     bool no_patchs2 = false;                     // ..._NO_PATCHS2: the strided 3x3 convs on conv_igemm.hip's generic tiles instead of conv_patchs2.hip
     bool x3_k2048 = false;                       // ..._X3_K2048: the deep-X 1x1 ring only from K = 2048 (the picker's rule before round 6) instead of from K = 1024 for 256-channel outputs
     bool lc1x1 = false;                          // ..._LC1X1 (opt-in, A/B): conv_persistlc.hip (loader / consumer 256 x 256 ring) wherever conv_persist.hip's residual-free and two-source forms run

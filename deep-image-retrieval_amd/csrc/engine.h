@@ -25,6 +25,7 @@ struct ConvLayer {
     uint16_t* d_w = nullptr;
     float* d_wf = nullptr;   // DIR_F32 (strict path, conv_f32.hip): the same layout in fp32; d_w stays null
     uint16_t* d_w_lo = nullptr;  // DIR_FP16P, the paired layers (stem, layer1; conv_pair.hip): fp16(w - fp16(w)), same layout
+    uint16_t* d_w_pw = nullptr;  // 3x3 stride-1 layers over >= 64 channels (conv_patchw.hip): d_w as that kernel's LDS stage images
     uint16_t* d_w_s2 = nullptr;  // 3x3 stride-2 layers (conv_patchs2.hip): d_w in that kernel's fragment order
     float* d_bias = nullptr;
     // conv3 of a stage's first block whose downsample qualifies (conv_c3c1.hip, DS form): this conv's

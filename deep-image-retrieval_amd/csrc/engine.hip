@@ -46,7 +46,7 @@ static Env read_env() {
     e.x3_k2048 = on("DIRTORCH_AMD_X3_K2048");
     e.no_patchs2 = on("DIRTORCH_AMD_NO_PATCHS2");
     e.patchw_pack = on("DIRTORCH_AMD_PATCHW_PACK");
-    e.persist_pack = on("DIRTORCH_AMD_PERSIST_PACK");
+    e.no_patchw_pack = on("DIRTORCH_AMD_NO_PATCHW_PACK");
     e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");
     e.no_x3 = on("DIRTORCH_AMD_NO_X3");
     e.no_patchs = on("DIRTORCH_AMD_NO_PATCHS");
@@ -298,6 +298,11 @@ int dir_engine::finalize(int dt) {
         }
         DIR_HIP_CHECK(hipMalloc((void**)&L.d_w, packed16.size() * 2));
         DIR_HIP_CHECK(hipMemcpy(L.d_w, packed16.data(), packed16.size() * 2, hipMemcpyHostToDevice));
+        if (!L.stem && L.R == 3 && L.S == 3 && L.stride == 1 && L.pad == 1 && L.Cin % 32 == 0 && L.Cin >= 64 && L.Cout % 128 == 0) {
+            // conv2 of layers 2-4: conv_patchw.hip's loaders copy their 24 KB weight stages as contiguous KBs from this copy
+            DIR_HIP_CHECK(hipMalloc((void**)&L.d_w_pw, packed16.size() * 2));
+            DIR_HIP_CHECK(conv_patch3x3w_pack(L.d_w, L.d_w_pw, L.Cout, L.Cin, nullptr));
+        }
         if (!L.stem && L.R == 3 && L.S == 3 && L.stride == 2 && L.pad == 1 && L.Cin % 64 == 0 && L.Cout % 128 == 0) {
             // conv2 of a stage's first block: conv_patchs2.hip reads its weight fragments as contiguous KBs from this copy
             DIR_HIP_CHECK(hipMalloc((void**)&L.d_w_s2, packed16.size() * 2));
@@ -430,7 +435,8 @@ void dir_engine::release() {
         if (L.d_w_lo) (void)hipFree(L.d_w_lo);
         L.d_w_lo = nullptr;
         if (L.d_w_s2) (void)hipFree(L.d_w_s2);
-        L.d_w_s2 = nullptr;
+        if (L.d_w_pw) (void)hipFree(L.d_w_pw);
+        L.d_w_s2 = L.d_w_pw = nullptr;
         if (L.d_bias) (void)hipFree(L.d_bias);
         if (L.d_w_ds) (void)hipFree(L.d_w_ds);
         if (L.d_w_ds_lo) (void)hipFree(L.d_w_ds_lo);
@@ -578,6 +584,7 @@ int dir_engine::run_conv(ConvLayer& L, const uint16_t* x, const uint16_t* res, u
     a.x = x;
     a.w = L.d_w;
     a.w_s2 = L.d_w_s2;
+    a.w_pw = env().no_patchw_pack ? nullptr : L.d_w_pw;
     a.bias = L.d_bias;
     a.res = res;
     a.y = y;

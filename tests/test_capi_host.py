@@ -206,7 +206,8 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
     # the strided 3x3 of layer2.0 (256^2 -> 128^2): the BK = 64 tile
     assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_patchs2', 1)      # (round 6: the strided patch kernel)
-    assert pick(32, 128, 256, 256, 3, 2, 0) == ('256x128_patchs2', 1) and pick(32, 64, 512, 512, 3, 2, 0) == ('256x128_patchs2', 1)
+    # ... only there: layer3.0 / 4.0's (256 / 512 channels) are matrix-bound and 10-15 % faster on the 16-wave tile (gpurun_out/r6s2b)
+    assert pick(32, 128, 256, 256, 3, 2, 0) == ('256x256_w4x4', 1) and pick(32, 64, 512, 512, 3, 2, 0) == ('256x256_w4x4', 1)
     assert pick(1, 256, 128, 128, 3, 2, 0)[0] != '256x128_patchs2'           # 64 tiles: too few for the persistent kernel
     assert pick(32, 64, 256, 1024, 1, 1, 0)[0] != '64x512_wreg1x1'
     assert pick(2, 64, 256, 1024, 1, 1, 1)[0] != '64x512_wreg1x1'
@@ -254,7 +255,7 @@ def test_profile_tooling_knows_every_engine_kernel():
     other = {'l2norm_rows_kernel', 'multiscale_pool_kernel', 'rank_sort_kernel', 'rank_hist_kernel', 'rank_finalize_kernel', 'revisitop_ap_kernel', 'expand_rows_kernel',
              'resample_coeffs_kernel', 'resample_pass_kernel', 'sim_split_kernel', 'sim_split_lc_kernel', 'split_queries_kernel', 'whiten_split_kernel', 'fill_noise_kernel',
              'gemm_splitk_finalize_kernel', 'conv_splitk_finalize_kernel', 'conv_naive_kernel',
-             'pack_patchs2_kernel', 'pack_patchw_kernel', 'pack_persist_kernel'}   # (filter re-ordering at finalize / in the per-op entry points)
+             'pack_patchs2_kernel', 'pack_patchw_kernel'}   # (filter re-ordering at finalize / in the per-op entry points)
     for n in names:
         k = S.bench_kernel_name(S.short(n))
         if 'conv' in n and 'finalize' not in n and 'naive' not in n:

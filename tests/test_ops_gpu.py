@@ -510,6 +510,57 @@ def test_conv_full_size_vs_device_checker(shape):
     assert torch.equal(y2, y1 * 2)
 
 
+@pytest.mark.parametrize('B,H,Cin,Cout', [(8, 256, 128, 128), (5, 121, 256, 256), (3, 127, 512, 512)],
+                         ids=['layer2.0.conv2_b8', 'layer3.0_ragged', 'layer4.0_odd'])
+def test_strided_patch_kernel_at_scale(B, H, Cin, Cout):
+    """conv_patchs2.hip (3x3 stride 2 from a 17 x 65 patch, even / odd input columns in separate runs, weight fragments from
+    the fragment-ordered copy) where every persistent workgroup walks several tiles and channel tiles alternate between them:
+    against the naive device checker element by element, and twice for run-to-run identity."""
+    ops = _ops()
+    names = ops.conv_variant_names()
+    for dname in ('bf16', 'fp16'):
+        dt = DTYPES[dname]
+        g = torch.Generator(device='cuda').manual_seed(41)
+        x = torch.relu(torch.randn(B, H, H + 3, Cin, generator=g, device='cuda')).to(dt)
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g, device='cuda') * (2.0 / (9 * Cin)) ** 0.5).to(dt)
+        bias = torch.randn(Cout, generator=g, device='cuda') * 0.1
+        kw = dict(stride=2, pad=1, relu=True)
+        got = ops.conv_bn_act(x, w, bias, None, variant=names.index('256x128_patchs2'), **kw)
+        ref = ops.conv_bn_act(x, w, bias, None, naive=True, **kw).float()
+        assert got.shape == (B, (H - 1) // 2 + 1, (H + 2) // 2 + 1, Cout)
+        err = (got.float() - ref).abs()
+        tol = RTOL[dname] * ref.abs() + RTOL[dname] * ref.abs().mean()
+        bad = err > tol
+        assert int(bad.sum()) == 0, '%s: bad elements %d, first bad pixel rows %s' % (
+            dname, int(bad.sum()), bad.flatten(0, 2).any(dim=1).nonzero()[:8].flatten().tolist())
+        assert torch.equal(got, ops.conv_bn_act(x, w, bias, None, variant=names.index('256x128_patchs2'), **kw))
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,use_res', [(1, 17, 18, 128, 128, False), (1, 9, 33, 512, 512, True), (2, 37, 33, 128, 256, True),
+                                                    (4, 64, 64, 256, 256, False)],
+                         ids=['c128', 'c512_res', 'tall_two_ntiles', 'layer3_b4'])
+def test_patchw_packed_weight_stages_equal_the_gather(B, H, W, Cin, Cout, use_res, monkeypatch):
+    """conv_patchw.hip's loaders copy each 24 KB weight stage as contiguous KBs from the filter re-ordered into the kernel's LDS
+    stage images (what the engine keeps per layer since finalize(); DIRTORCH_AMD_PATCHW_PACK makes the per-op entry point pack into
+    scratch) instead of gathering 64-byte runs of [Cout][3][3][Cin]: the same bytes land in the same LDS slots - bit for bit."""
+    ops = _ops()
+    v = ops.conv_variant_names().index('512x128_patch3x3w')
+    for dname in ('bf16', 'fp16'):
+        dt = DTYPES[dname]
+        g = torch.Generator(device='cuda').manual_seed(43)
+        x = torch.randn(B, H, W, Cin, generator=g, device='cuda').to(dt)
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g, device='cuda') * (2.0 / (9 * Cin)) ** 0.5).to(dt)
+        bias = torch.randn(Cout, generator=g, device='cuda') * 0.1
+        res = torch.randn(B, H, W, Cout, generator=g, device='cuda').to(dt) if use_res else None
+        kw = dict(stride=1, pad=1, relu=True, variant=v)
+        plain = ops.conv_bn_act(x, w, bias, res, **kw)
+        monkeypatch.setenv('DIRTORCH_AMD_PATCHW_PACK', '1')
+        packed = ops.conv_bn_act(x, w, bias, res, **kw)
+        monkeypatch.delenv('DIRTORCH_AMD_PATCHW_PACK')
+        assert torch.equal(plain, packed), dname
+        assert float(plain.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize('B,HW,Cin,Cout,stride', [(32, 64, 1024, 256, 1), (31, 63, 1024, 256, 1), (8, 128, 512, 1024, 2),
                                                   (16, 32, 2048, 512, 1)],
                          ids=['layer3.conv1_b32', 'ragged', 'layer3.0.downsample', 'layer4.conv1'])

@@ -170,11 +170,11 @@ def test_trunk_tiles_at_headline_size(dtype):
 TIMED_MIX = {
     32: {'layer2.1.conv2': '512x128_patch3x3w', 'layer3.7.conv2': '512x128_patch3x3w', 'layer4.1.conv2': '512x128_patch3x3w',
          'layer2.3.conv3': '64x512_wreg1x1', 'layer3.9.conv3': '64x512_wreg1x1',
-         'layer3.5.conv1': '256x256_persist1x1', 'layer4.2.conv3': '256x256_persist1x1',
-         'layer4.1.conv1': '256x256_persist1x1_x3'},
+         'layer3.5.conv1': '256x256_persist1x1_x3', 'layer4.2.conv3': '256x256_persist1x1',
+         'layer4.1.conv1': '256x256_persist1x1_x3', 'layer2.0.conv2': '256x128_patchs2', 'layer3.0.conv2': '256x256_w4x4'},
     16: {'layer2.1.conv2': '512x128_patch3x3w', 'layer3.7.conv2': '512x128_patch3x3w',
          'layer2.3.conv3': '64x512_wreg1x1', 'layer3.9.conv3': '64x512_wreg1x1',
-         'layer3.5.conv1': '256x256_persist1x1'},
+         'layer3.5.conv1': '256x256_persist1x1_x3', 'layer2.0.conv2': '256x128_patchs2'},
 }
 ROWS = {32: (0, 13, 31), 16: (0, 13)}     # batch 16 = the first 16 images of the batch-32 case: rows 0 and 13 reuse its oracle results
 
