@@ -113,7 +113,6 @@ hipError_t conv_patch3x3w_pack(const uint16_t* w, uint16_t* out, int Cout, int C
 bool conv_patch3x3s2_admissible(const ConvArgs& a);   // conv_patchs2.hip: 3x3 stride 2
 hipError_t conv_patch3x3s2_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 hipError_t conv_patch3x3s2_pack(const uint16_t* w, uint16_t* out, int Cout, int Cin, hipStream_t stream);   // same size as w
-int conv_patch3x3s2_plane(int Cin);   // plane depth (32 / 64 channels) of the form that runs for this Cin
 bool conv_patch3x3_admissible(const ConvArgs& a);
 hipError_t conv_patch3x3_launch(const ConvArgs& a, int dtype, hipStream_t stream);
 

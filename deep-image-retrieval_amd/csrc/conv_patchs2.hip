@@ -33,22 +33,14 @@ __device__ __forceinline__ void dma16s2(__amdgpu_buffer_rsrc_t rsrc, char* lds, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (DIR_LDS void*)lds, 16, voff, soff, 0, 0);
 }
 
-// <PD, TH>: plane depth in channels, output rows per tile.  <32, 8> is the form described above; <64, 4> (a 9 x 65 patch in 64-channel
-// planes of 74 KB, slots of 128 bytes swizzled by (c >> 1) & 7, two output rows per consumer wave) is the one for 128 input channels:
-// there the launch is bound by HBM, and with 64-byte slots two consecutive planes share every 128-byte line of the input - the second
-// read finds a part of them evicted (PMC traffic 1.55x the tensors, profiles/r06_late_kernels.txt).  Whole lines per request also
-// halve the request count; the price is the weight stream per output (twice: half as many pixels per tile).
-template <class DT, int PD, int TH>
+template <class DT>
 __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) {
-    constexpr int TW = 32, PH = 2 * TH + 1, PW = 2 * TW + 1, PP = PH * PW;   // 17 x 65 = 1105 (9 x 65 = 585) patch pixels
+    constexpr int TH = 8, TW = 32, PH = 2 * TH + 1, PW = 2 * TW + 1, PP = PH * PW;   // 17 x 65 = 1105 patch pixels
     constexpr int NEV = TW + 1;                           // even-column run of a row: slots 0 .. 32; odd columns: 33 .. 64
-    constexpr int SB = PD * 2, CH = SB / 16, SPP = 64 / CH;   // slot bytes, 16-byte chunks per slot, slots per 1 KB DMA piece
-    constexpr int KK = PD / 16, RW = TH / 2;              // K sub-steps per plane, output rows per consumer wave
-    constexpr int NPIECE = (PP + SPP - 1) / SPP;          // 70 (74) DMA pieces
-    constexpr int NL = 4, LP = (NPIECE + NL - 1) / NL;    // 18 (19) pieces per loader wave and plane
-    constexpr int PBUF = NPIECE * 1024;                   // 71 680 (75 776)
+    constexpr int NPIECE = (PP + 15) / 16;                // 70 DMA pieces of 16 slots x 64 B
+    constexpr int NL = 4, LP = (NPIECE + NL - 1) / NL;    // 18 pieces per loader wave and plane
+    constexpr int PBUF = NPIECE * 1024;                   // 71 680
     constexpr int BN = 128;
-    static_assert((PD == 32 || PD == 64) && RW * KK == 8, "72 MFMAs per wave and plane in both forms");
     typedef typename DT::frag_t frag_t;
     static_assert(2 * PBUF <= 160 * 1024, "LDS map");
 
@@ -59,7 +51,7 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
 
-    const int NQ = a.Cin / PD;                 // planes per tile (even: the launcher checks)
+    const int NQ = a.Cin / 32;                 // planes per tile (even: Cin % 64 == 0)
     const int tiles_n = a.Cout / BN;
     const int tiles_x = (a.OW + TW - 1) / TW;
     const int tiles_y = (a.OH + TH - 1) / TH;
@@ -77,10 +69,10 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
 #pragma unroll
         for (int k = 0; k < LP; ++k) {
             const int piece = k * NL + lw;
-            const int p = piece * SPP + lane / CH;
+            const int p = piece * 16 + (lane >> 2);
             const int py = p / PW, c = p - py * PW;
             const int px = c < NEV ? 2 * c : 2 * (c - NEV) + 1;
-            const int chunk = (lane & (CH - 1)) ^ (PD == 32 ? (c >> 2) & 3 : (c >> 1) & 7);
+            const int chunk = (lane & 3) ^ ((c >> 2) & 3);
             ppos[k] = (piece < NPIECE && p < PP) ? (py << 16) | (px << 4) | chunk : -1;
         }
         uint32_t pvoff[LP];
@@ -102,7 +94,7 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
             char* dst = smem + buf * PBUF;
 #pragma unroll
             for (int k = 0; k < LP; ++k)
-                if (k * NL + lw < NPIECE) dma16s2(rsrc_x, dst + (k * NL + lw) * 1024, pvoff[k], q * SB);
+                if (k * NL + lw < NPIECE) dma16s2(rsrc_x, dst + (k * NL + lw) * 1024, pvoff[k], q * 64);
         };
         const int NG = my_tiles * NQ;
         int it = 0, q = 0;
@@ -127,25 +119,24 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
     const int ct = wave & 3, rh = wave >> 2;
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_s2, 0, a.w_bytes, 0x00020000);
     const uint32_t wvoff = (uint32_t)(lane * 16);
-    frag_t W[2][3][KK];   // two sets (this filter row / the next one) x tap x K sub-step
-    auto load_w = [&](frag_t (&w)[3][KK], int tile_n, int q, int r) __attribute__((always_inline)) {
-        const int blk = ((((tile_n * NQ + q) * 3 + r) * 4 + ct) * (3 * KK)) * 1024;   // pack_patchs2_kernel's order
+    frag_t W[2][3][2];   // two sets (this filter row / the next one) x tap x K half
+    auto load_w = [&](frag_t (&w)[3][2], int tile_n, int q, int r) __attribute__((always_inline)) {
+        const int blk = ((((tile_n * NQ + q) * 3 + r) * 4 + ct) * 6) * 1024;   // pack_patchs2_kernel's order
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-                w[s][kk] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff, blk + (s * KK + kk) * 1024, 0));
+            for (int kk = 0; kk < 2; ++kk)
+                w[s][kk] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wvoff, blk + (s * 2 + kk) * 1024, 0));
     };
     // fragment of output row j (of this wave's four), filter row r, tap s: slot (2 (4 rh + j) + r) * 65 + c, c = {0, 33, 1}[s] + lrow;
     // its 16-byte chunks are swizzled by the slot's index IN ITS ROW, (c >> 2) & 3, so that a lane has one address per (tap, K half)
     // and the rows are immediate offsets
-    const char* xbase[3][KK];
+    const char* xbase[3][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int c = (s == 1 ? NEV : (s >> 1)) + lrow;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-            xbase[s][kk] = smem + ((2 * RW * rh) * PW + c) * SB + (((2 * kk + lhi) ^ (PD == 32 ? (c >> 2) & 3 : (c >> 1) & 7)) << 4);
+        for (int kk = 0; kk < 2; ++kk) xbase[s][kk] = smem + ((2 * 4 * rh) * PW + c) * 64 + (((2 * kk + lhi) ^ ((c >> 2) & 3)) << 4);
     }
 
     Ovf<DT> ovf;
@@ -154,12 +145,12 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
         const int tile = first + it * G;
         const int tile_n = tile % tiles_n;
         const int tn_next = it + 1 < my_tiles ? (tile + G) % tiles_n : tile_n;
-        f32x16_t acc[RW];
+        f32x16_t acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4_t b4 = *(const DIR_GLOBAL f32x4_t*)(a.bias + tile_n * BN + ct * 32 + 8 * g + 4 * lhi);
 #pragma unroll
-            for (int j = 0; j < RW; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = b4[e];
         }
@@ -182,12 +173,12 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) {
-                        frag_t xf[RW];
+                    for (int kk = 0; kk < 2; ++kk) {
+                        frag_t xf[4];
 #pragma unroll
-                        for (int j = 0; j < RW; ++j) xf[j] = *(const frag_t*)(xbase[s][kk] + PAR * PBUF + (2 * j + r) * (PW * SB));
+                        for (int j = 0; j < 4; ++j) xf[j] = *(const frag_t*)(xbase[s][kk] + PAR * PBUF + (2 * j + r) * (PW * 64));
 #pragma unroll
-                        for (int j = 0; j < RW; ++j) acc[j] = DT::mfma32(W[cur][s][kk], xf[j], acc[j]);
+                        for (int j = 0; j < 4; ++j) acc[j] = DT::mfma32(W[cur][s][kk], xf[j], acc[j]);
                     }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this plane's LDS reads retired before the next barrier
@@ -205,8 +196,8 @@ __global__ void __launch_bounds__(768) conv_patch3x3s2_kernel(const ConvArgs a) 
         const int b = t / tiles_y;
         const int ox = tx * TW + lrow;
 #pragma unroll
-        for (int j = 0; j < RW; ++j) {
-            const int oy = ty * TH + rh * RW + j;
+        for (int j = 0; j < 4; ++j) {
+            const int oy = ty * TH + rh * 4 + j;
             const bool ok = oy < a.OH && ox < a.OW;
             uint16_t* yrow = a.y + ((size_t)((b * a.OH + (ok ? oy : 0)) * a.OW + (ok ? ox : 0)) * a.Cout + tile_n * BN + ct * 32 + lhi * 8);
 #pragma unroll
@@ -242,44 +233,40 @@ bool conv_patch3x3s2_admissible(const ConvArgs& a) {
            (size_t)a.B * a.H * a.W * a.Cin * 2 < (1ull << 31) && (size_t)a.Cout * a.Ktot * 2 < (1ull << 31);
 }
 
-// The filter in the order the consumers read it (PD = the plane depth of the form that will run, conv_patch3x3s2_plane(Cin); KK = PD / 16):
-// 16-byte piece ((((tile_n * NQ + q) * 3 + r) * 4 + ct) * 3 KK + s * KK + kk) * 64 + lane
-// = w[tile_n * 128 + ct * 32 + (lane & 31)][r][s][q * PD + kk * 16 + (lane >> 5) * 8 .. + 8]  (same bytes, same size).
-__global__ void __launch_bounds__(256) pack_patchs2_kernel(const uint16_t* w, uint16_t* out, int Cout, int Cin, int PD) {
-    const int NQ = Cin / PD, KK = PD / 16;
+// The filter in the order the consumers read it: 16-byte piece ((((tile_n * NQ + q) * 3 + r) * 4 + ct) * 6 + s * 2 + kk) * 64 + lane
+// = w[tile_n * 128 + ct * 32 + (lane & 31)][r][s][q * 32 + kk * 16 + (lane >> 5) * 8 .. + 8]  (same bytes, same size).
+__global__ void __launch_bounds__(256) pack_patchs2_kernel(const uint16_t* w, uint16_t* out, int Cout, int Cin) {
+    const int NQ = Cin / 32;
     const long pieces = (long)Cout * 9 * Cin / 8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (long)gridDim.x * 256) {
         long t = i;
         const int lane = (int)(t & 63);
         t >>= 6;
-        const int sk = (int)(t % (3 * KK));
-        t /= 3 * KK;
+        const int sk = (int)(t % 6);
+        t /= 6;
         const int ct = (int)(t & 3);
         t >>= 2;
         const int r = (int)(t % 3);
         t /= 3;
         const int q = (int)(t % NQ);
         const int tn = (int)(t / NQ);
-        const int s = sk / KK, kk = sk - s * KK;
-        const size_t src = ((size_t)((tn * 128 + ct * 32 + (lane & 31)) * 9 + r * 3 + s)) * Cin + q * PD + kk * 16 + (lane >> 5) * 8;
+        const int s = sk >> 1, kk = sk & 1;
+        const size_t src = ((size_t)((tn * 128 + ct * 32 + (lane & 31)) * 9 + r * 3 + s)) * Cin + q * 32 + kk * 16 + (lane >> 5) * 8;
         gstore16(out + i * 8, gload16(w + src));
     }
 }
 
-// 64-channel planes x 4-row tiles for 128 input channels (the HBM-bound first strided conv), 32-channel planes x 8-row tiles otherwise
-int conv_patch3x3s2_plane(int Cin) { return Cin == 128 && !env().patchs2_a ? 64 : 32; }
-
 hipError_t conv_patch3x3s2_pack(const uint16_t* w, uint16_t* out, int Cout, int Cin, hipStream_t stream) {
     const long pieces = (long)Cout * 9 * Cin / 8;
     const int grid = (int)((pieces + 255) / 256 < 1024 ? (pieces + 255) / 256 : 1024);
-    hipLaunchKernelGGL(pack_patchs2_kernel, dim3(grid), dim3(256), 0, stream, w, out, Cout, Cin, conv_patch3x3s2_plane(Cin));
+    hipLaunchKernelGGL(pack_patchs2_kernel, dim3(grid), dim3(256), 0, stream, w, out, Cout, Cin);
     return hipGetLastError();
 }
 
-template <class DT, int PD, int TH>
+template <class DT>
 static hipError_t launch_patch_s2(const ConvArgs& a, hipStream_t stream) {
-    constexpr int LDS = 2 * (PD == 32 ? 70 : 74) * 1024;
-    auto kern = conv_patch3x3s2_kernel<DT, PD, TH>;
+    constexpr int LDS = 2 * 70 * 1024;
+    auto kern = conv_patch3x3s2_kernel<DT>;
     static std::atomic<uint64_t> attr_done{0};
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_done); e != hipSuccess) return e;
     ConvArgs b = a;
@@ -294,7 +281,7 @@ static hipError_t launch_patch_s2(const ConvArgs& a, hipStream_t stream) {
         }
         b.w_s2 = (const uint16_t*)scratch;
     }
-    const long tiles = (long)a.B * ((a.OH + TH - 1) / TH) * ((a.OW + 31) / 32) * (a.Cout / 128);
+    const long tiles = (long)a.B * ((a.OH + 7) / 8) * ((a.OW + 31) / 32) * (a.Cout / 128);
     const int ncu = cu_count();
     const int grid = tiles < ncu ? (int)tiles : ncu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(768), LDS, stream, b);
@@ -307,9 +294,7 @@ static hipError_t launch_patch_s2(const ConvArgs& a, hipStream_t stream) {
 }
 
 hipError_t conv_patch3x3s2_launch(const ConvArgs& a, int dtype, hipStream_t stream) {
-    if (conv_patch3x3s2_plane(a.Cin) == 64)
-        return dtype == DIR_BF16 ? launch_patch_s2<BF16, 64, 4>(a, stream) : launch_patch_s2<FP16, 64, 4>(a, stream);
-    return dtype == DIR_BF16 ? launch_patch_s2<BF16, 32, 8>(a, stream) : launch_patch_s2<FP16, 32, 8>(a, stream);
+    return dtype == DIR_BF16 ? launch_patch_s2<BF16>(a, stream) : launch_patch_s2<FP16>(a, stream);
 }
 
 }  // namespace dir
