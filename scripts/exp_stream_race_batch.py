@@ -23,7 +23,7 @@ refs = [net(x).clone() for x in imgs]
 kernels = sorted({r['kernel'] for r in net.get_profile()})
 net.set_profiling(False)
 torch.cuda.synchronize()
-print('kernel mix:', [k for k in kernels if 'patch3x3w' in k or 'c3c1' in k or 'wreg' in k])
+print('kernel mix:', [k for k in kernels if 'patch3x3w' in k or 'patchs2' in k or 'c3c1' in k or 'wreg' in k])
 for ns in (1, 2, 3):
     pool = StreamPool(ns)
     outs = []
