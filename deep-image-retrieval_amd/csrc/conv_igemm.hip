@@ -660,13 +660,33 @@ int conv_pick_variant(const ConvArgs& a) {
             if (t64x128 < 192 && t64 >= 192 && v2 >= 0 && conv_variant_admissible(v2, a)) return v2;
         }
     }
+    // Ragged maps (round 6, distilled from the tuner on configs[4]'s three scales, scripts/exp_multiscale_tune.py): the 16 x 32-pixel
+    // patch tile wastes what a map leaves of its last tiles (107^2: 20 %, 54^2: 29 %, 38^2: 53 %) where the implicit-GEMM tile walks
+    // the flattened pixels; both lose the idle part of their last round of workgroups.  With the 16-wave tile at 0.91 of the patch
+    // kernel's rate on full tiles (133 vs 121 us on layer3 at batch 32): 16 x 107^2 x 256 channels 0.70 vs 0.85 -> the flattened tile
+    // (tuner: 216 -> 201 us), 16 x 75^2 0.69 vs 0.63 and 16 x 54^2 0.71 vs 0.65 -> the patch kernel (tuner: the same), 16 x 38^2 x 512
+    // 0.35 vs 0.65 -> the flattened tile.  DIRTORCH_AMD_NO_SMALLMAP switches this off with the other distilled rules.
+    const int v_pw = find_variant("512x128_patch3x3w");
+    long pw_wgs = 0;
+    if (v_pw >= 0 && a.R * a.S > 1 && a.Cin >= 128 && !env().no_patchw && conv_variant_admissible(v_pw, a)) {
+        pw_wgs = (long)a.B * ceil_div(a.OH, 16) * ceil_div(a.OW, 32) * (a.Cout / 128);
+        const int v_g = find_variant("256x256_w4x4");
+        if (!env().no_smallmap && a.Cout % 256 == 0 && v_g >= 0 && conv_variant_admissible(v_g, a)) {
+            auto round_eff = [](long wgs) { return (double)wgs / (double)(ceil_div((int)wgs, 256) * 256L); };
+            const long t256 = (long)ceil_div(a.M, 256) * (a.Cout / 256);
+            const double eff_p = (double)a.M / ((double)(pw_wgs / (a.Cout / 128)) * 512.0) * round_eff(pw_wgs);
+            const double eff_g = 0.91 * round_eff(t256);
+            if (t256 >= 176 && eff_g > 1.05 * eff_p) return v_g;
+        }
+    }
     int last = -1, prev = -1;
     for (int i = 0; i < n; ++i) {
         const int v = find_variant(c[i].name);
         if (v < 0 || !conv_variant_admissible(v, a)) continue;
         prev = last;
         last = v;
-        const long tiles = (long)ceil_div(a.M, kVariants[v].BM) * (a.Cout / kVariants[v].BN);
+        // (the patch kernel's workgroups are per-image tiles: on a ragged map more than ceil(M / 512))
+        const long tiles = v == v_pw && pw_wgs && !env().no_smallmap ? pw_wgs : (long)ceil_div(a.M, kVariants[v].BM) * (a.Cout / kVariants[v].BN);
         if (tiles >= 192L * c[i].wg_per_cu) return v;
     }
     // nothing fills the chip: the smallest tile, unless it is the split-K fallback of a list whose

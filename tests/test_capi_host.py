@@ -203,6 +203,11 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     # between the two regimes (batch 4 here; ResNet-50 at 64 x 224^2 has the same pixel counts): 64 x 128 tiles, two workgroups per CU
     assert pick(4, *shapes['l3.conv1']) == ('64x128_w2x2', 1) and pick(4, *shapes['l3.conv2']) == ('64x128_w2x2', 1)
     assert pick(8, *shapes['l3.conv2']) == ('128x128_w2x2', 1)
+    # ragged maps (configs[4]'s scales at batch 16): the patch tile wastes the rest of a map's last tiles, the flattened 16-wave tile
+    # does not - the picker weighs tile fill x round fill of both (round 6, from the tuner: scripts/exp_multiscale_tune.py)
+    assert pick(16, 107, 256, 256, 3, 1, 0) == ('256x256_w4x4', 1) and pick(16, 38, 512, 512, 3, 1, 0) == ('256x256_w4x4', 1)
+    assert pick(16, 75, 256, 256, 3, 1, 0) == ('512x128_patch3x3w', 1) and pick(16, 54, 256, 256, 3, 1, 0) == ('512x128_patch3x3w', 1)
+    assert pick(16, 54, 512, 512, 3, 1, 0) == ('512x128_patch3x3w', 1) and pick(16, 150, 128, 128, 3, 1, 0) == ('512x128_patch3x3w', 1)
     # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
     # the strided 3x3 of layer2.0 (256^2 -> 128^2): the BK = 64 tile
     assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_patchs2', 1)      # (round 6: the strided patch kernel)
