@@ -667,17 +667,19 @@ int conv_pick_variant(const ConvArgs& a) {
     // (tuner: 216 -> 201 us), 16 x 75^2 0.69 vs 0.63 and 16 x 54^2 0.71 vs 0.65 -> the patch kernel (tuner: the same), 16 x 38^2 x 512
     // 0.35 vs 0.65 -> the flattened tile.  DIRTORCH_AMD_NO_SMALLMAP switches this off with the other distilled rules.
     const int v_pw = find_variant("512x128_patch3x3w");
-    long pw_wgs = 0;
+    long pw_wgs = 0;   // (set when the map fills at least 60 % of its tiles: a 7 x 7 map's one tile per image is no workgroup to count)
     if (v_pw >= 0 && a.R * a.S > 1 && a.Cin >= 128 && !env().no_patchw && conv_variant_admissible(v_pw, a)) {
         pw_wgs = (long)a.B * ceil_div(a.OH, 16) * ceil_div(a.OW, 32) * (a.Cout / 128);
+        const double fill = (double)a.M / ((double)(pw_wgs / (a.Cout / 128)) * 512.0);
         const int v_g = find_variant("256x256_w4x4");
         if (!env().no_smallmap && a.Cout % 256 == 0 && v_g >= 0 && conv_variant_admissible(v_g, a)) {
             auto round_eff = [](long wgs) { return (double)wgs / (double)(ceil_div((int)wgs, 256) * 256L); };
             const long t256 = (long)ceil_div(a.M, 256) * (a.Cout / 256);
-            const double eff_p = (double)a.M / ((double)(pw_wgs / (a.Cout / 128)) * 512.0) * round_eff(pw_wgs);
+            const double eff_p = fill * round_eff(pw_wgs);
             const double eff_g = 0.91 * round_eff(t256);
             if (t256 >= 176 && eff_g > 1.05 * eff_p) return v_g;
         }
+        if (fill < 0.6) pw_wgs = 0;
     }
     int last = -1, prev = -1;
     for (int i = 0; i < n; ++i) {

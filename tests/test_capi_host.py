@@ -208,6 +208,14 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     assert pick(16, 107, 256, 256, 3, 1, 0) == ('256x256_w4x4', 1) and pick(16, 38, 512, 512, 3, 1, 0) == ('256x256_w4x4', 1)
     assert pick(16, 75, 256, 256, 3, 1, 0) == ('512x128_patch3x3w', 1) and pick(16, 54, 256, 256, 3, 1, 0) == ('512x128_patch3x3w', 1)
     assert pick(16, 54, 512, 512, 3, 1, 0) == ('512x128_patch3x3w', 1) and pick(16, 150, 128, 128, 3, 1, 0) == ('512x128_patch3x3w', 1)
+    # ... and a map that fills a fraction of ONE tile per image is no reason to count that tile as a workgroup (config A's layer4: 64 x 7^2)
+    assert pick(64, 7, 512, 512, 3, 1, 0) == ('64x128_w2x2_s4', 1) and pick(128, 7, 512, 512, 3, 1, 0)[0] != '512x128_patch3x3w'
+    for B_ in (1, 4, 16, 64, 256):
+        for H_ in (5, 7, 9, 14, 19, 27, 38):
+            for C_ in (128, 256, 512):
+                name_, _ = pick(B_, H_, C_, C_, 3, 1, 0)
+                fill = H_ * H_ / float(-(-H_ // 16) * 16 * -(-H_ // 32) * 32)
+                assert name_ != '512x128_patch3x3w' or fill >= 0.6 or B_ * H_ * H_ >= 192 * 512 // (C_ // 128), (B_, H_, C_, name_)
     # the register-stationary kernel needs a residual and enough pixel tiles per persistent workgroup
     # the strided 3x3 of layer2.0 (256^2 -> 128^2): the BK = 64 tile
     assert pick(32, 256, 128, 128, 3, 2, 0) == ('256x128_patchs2', 1)      # (round 6: the strided patch kernel)
