@@ -655,9 +655,24 @@ int conv_pick_variant(const ConvArgs& a) {
         const long t256 = (long)ceil_div(a.M, 256) * (a.Cout / 256), t128 = (long)ceil_div(a.M, 128) * (a.Cout / 128);
         const long t64x128 = (long)ceil_div(a.M, 64) * (a.Cout / 128), t64 = (long)ceil_div(a.M, 64) * (a.Cout / 64);
         if (t256 < 192 && t128 < 512) {
-            const int v1 = find_variant("64x128_w2x2"), v2 = find_variant("64x64_w2x2_s4");
+            const int v1 = find_variant("64x128_w2x2"), v2 = find_variant("64x64_w2x2_s4"), v3 = find_variant("64x64_small_s4k2");
+            const bool ok2 = v2 >= 0 && conv_variant_admissible(v2, a), ok3 = v3 >= 0 && conv_variant_admissible(v3, a);
             if (t64x128 >= 256 && v1 >= 0 && conv_variant_admissible(v1, a)) return v1;
-            if (t64x128 < 192 && t64 >= 192 && v2 >= 0 && conv_variant_admissible(v2, a)) return v2;
+            if (t64x128 < 192 && t64 >= 192) {
+                // (conv_small.hip's two-K-steps-per-stage tile is 8 % faster here on ONE stream - batch 1 at 1024^2 777 -> 839 img/s -
+                // and, at 128 KB of LDS, 3-4 % slower on two to four: DIRTORCH_AMD_SMALL_K2 for callers that do not overlap forwards)
+                if (env().small_k2 && ok3) return v3;
+                if (ok2) return v2;
+            }
+            // Below 192 tiles of 64 x 64 the list further down fell to split-K on 64 x 128 tiles - a cliff native-size images sit right
+            // under (683 x 1024: 43 x 64 pixels in layer3 = 172 tiles; the tuner, scripts/exp_batch1_tune.py: 16 -> 10 us per conv1).
+            // conv_small.hip with two K-steps per stage instead, down to 32 tiles (layer4's 2048 -> 512 conv1 at 1024^2: 19 -> 14 us);
+            // gpurun_out/r6b1rules, img/s on 1 / 2 / 4 streams: 683 x 1024 760 / 1128 / 1097 -> 960 / 1330 / 1287, 500 x 375 1010 /
+            // 1590 / 1550 -> 1137 / 2100 / 2094, nothing lost at 1024^2 or 768 x 1024.  (K >= 4096, layer4's 3x3, keeps split-K.)
+            if (t64x128 < 192 && t64 >= 32 && t64 < 192 && T < 64) {
+                if (ok3) return v3;
+                if (ok2) return v2;
+            }
         }
     }
     // Ragged maps (round 6, distilled from the tuner on configs[4]'s three scales, scripts/exp_multiscale_tune.py): the 16 x 32-pixel

@@ -48,6 +48,7 @@ struct Env {
     bool unfused_stem = false, stem_v1 = false;  // ..._UNFUSED_STEM, ..._STEM_V1: conv + maxpool apart / one tile per workgroup
     bool no_patchlc = false, no_wreg = false, no_patchw = false, no_x3 = false, no_patchs = false;   // heuristic: skip a kernel
     bool patchw_pack = false, no_patchw_pack = false;   // ..._PATCHW_PACK: per-op conv_patchw.hip launches pack the filter into stage images (stream-ordered scratch); ..._NO_PATCHW_PACK: the engine's launches gather from the [Cout][3][3][Cin] layout again
+    bool small_k2 = false;                       // ..._SMALL_K2: small maps with >= 192 tiles of 64 x 64 on conv_small.hip's 128 KB two-K-steps-per-stage tile too (one-stream callers: +8 %; two to four streams: -3 %)
     bool no_patchs2 = false;                     // ..._NO_PATCHS2: the strided 3x3 convs on conv_igemm.hip's generic tiles instead of conv_patchs2.hip
     bool x3_k2048 = false;                       // ..._X3_K2048: the deep-X 1x1 ring only from K = 2048 (the picker's rule before round 6) instead of from K = 1024 for 256-channel outputs
     bool lc1x1 = false;                          // ..._LC1X1 (opt-in, A/B): conv_persistlc.hip (loader / consumer 256 x 256 ring) wherever conv_persist.hip's residual-free and two-source forms run

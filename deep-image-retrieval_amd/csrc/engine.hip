@@ -45,6 +45,7 @@ static Env read_env() {
     e.lc1x1 = on("DIRTORCH_AMD_LC1X1");
     e.x3_k2048 = on("DIRTORCH_AMD_X3_K2048");
     e.no_patchs2 = on("DIRTORCH_AMD_NO_PATCHS2");
+    e.small_k2 = on("DIRTORCH_AMD_SMALL_K2");
     e.patchw_pack = on("DIRTORCH_AMD_PATCHW_PACK");
     e.no_patchw_pack = on("DIRTORCH_AMD_NO_PATCHW_PACK");
     e.no_patchw = on("DIRTORCH_AMD_NO_PATCHW");

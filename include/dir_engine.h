@@ -111,7 +111,7 @@ const char* dir_version(void);
  *       _REV_CONV1 / _REV_CONV3, _UNFUSED_STEM, _PAIR_ACTS, _PAIR_STAGES (the last two take effect at dir_engine_finalize),
  *       _NO_INPLACE, _NO_STEM_U8, _STEM_U8_SEG, _EXPERIMENTS (which kernels a forward may consider)
  *   per PROCESS (read from the current snapshot at every launch, by engines and by the per-op entry points alike):  the kernel
- *       pickers' _NO_PATCHLC / _NO_WREG / _NO_WREGD / _NO_SMALLMAP / _NO_C3C1LC / _LC1X1 / _X3_K2048 / _NO_PATCHS2 / _PATCHW_PACK / _NO_PATCHW_PACK / _NO_PATCHW / _NO_PATCHW_LC / _NO_X3 / _NO_PATCHS / _NO_PAIR_PATCH / _NO_XCDMAP,
+ *       pickers' _NO_PATCHLC / _NO_WREG / _NO_WREGD / _NO_SMALLMAP / _SMALL_K2 / _NO_C3C1LC / _LC1X1 / _X3_K2048 / _NO_PATCHS2 / _PATCHW_PACK / _NO_PATCHW_PACK / _NO_PATCHW / _NO_PATCHW_LC / _NO_X3 / _NO_PATCHS / _NO_PAIR_PATCH / _NO_XCDMAP,
  *       _STEM_V1, _STEM_PAIR_OLD, _STEM_U8_PREP, _STEM_U8_WG8, _SIM_V1, _SIM_EXACT
  * The re-read builds a new snapshot and publishes it with one atomic store (a launch sees the old set or the new one, never a
  * mixture); still, do not call it while another thread is launching if that thread's A/B comparison matters. */

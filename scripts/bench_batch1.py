@@ -32,11 +32,12 @@ def main():
     net.compute_dtype = args.dtype
     net.cuda().eval()
     res = {'dtype': args.dtype, 'arch': args.arch}
-    for H, W in ((1024, 1024), (768, 1024)):
+    sizes = [tuple(int(v) for v in t.split('x')) for t in os.environ['B1_SIZES'].split(',')] if os.environ.get('B1_SIZES') else ((1024, 1024), (768, 1024))
+    for H, W in sizes:
         g = torch.Generator(device='cuda').manual_seed(3)
         imgs = [torch.randint(0, 256, (1, H, W, 3), generator=g, dtype=torch.uint8, device='cuda') for _ in range(8)]
         ref = None
-        for ns in (1, 2, 3, 4, 6):
+        for ns in ([int(v) for v in os.environ['B1_STREAMS'].split(',')] if os.environ.get('B1_STREAMS') else (1, 2, 3, 4, 6)):
             pool = StreamPool(ns)
             outs = []
             for rep in range(2):            # first pass: workspaces, lazy kernel attributes

@@ -196,10 +196,15 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
         assert pick(32, *s) == (batch32[name], 1), name
     batch1 = {    # small M: deep-ring small tiles, split-K where even those leave CUs idle
         'l2.conv2': ('64x128_w2x2_s4', 1), 'l3.conv1': ('64x64_w2x2_s4', 1), 'l3.conv2': ('64x64_w2x2_s4', 1),   # (round 6: one 64 x 64 tile per CU, 64 KB of LDS)
-        'l3.conv3': ('128x128_w2x2', 1), 'l4.conv1': ('64x128_w2x2', 8), 'l4.conv2': ('64x128_w2x2', 8),
+        'l3.conv3': ('128x128_w2x2', 1), 'l4.conv1': ('64x64_small_s4k2', 1), 'l4.conv2': ('64x128_w2x2', 8),   # (round 6, late: 128 tiles of 64 x 64 - conv_small.hip's two-K-steps-per-stage tile instead of split-K; K = 4608 keeps split-K)
     }
     for name, want in batch1.items():
         assert pick(1, *shapes[name]) == want, name
+    # native-size images sit right under the 192-tile line (683 x 1024 -> 43 x 64 pixels in layer3; here 52^2 = 2 704 pixels, 172 tiles):
+    # no split-K cliff there (round 6, from the tuner at batch 1: scripts/exp_batch1_tune.py, A/B on 1 / 2 / 4 streams gpurun_out/r6b1rules)
+    assert pick(1, 52, 1024, 256, 1, 1, 0) == ('64x64_small_s4k2', 1) and pick(1, 52, 256, 256, 3, 1, 0) == ('64x64_small_s4k2', 1)
+    assert pick(1, 28, 1024, 256, 1, 1, 0) == ('64x64_small_s4k2', 1)        # 52 tiles
+    assert pick(1, 16, 1024, 256, 1, 1, 0)[0] != '64x64_small_s4k2'          # 16 tiles: split-K stays
     # between the two regimes (batch 4 here; ResNet-50 at 64 x 224^2 has the same pixel counts): 64 x 128 tiles, two workgroups per CU
     assert pick(4, *shapes['l3.conv1']) == ('64x128_w2x2', 1) and pick(4, *shapes['l3.conv2']) == ('64x128_w2x2', 1)
     assert pick(8, *shapes['l3.conv2']) == ('128x128_w2x2', 1)
