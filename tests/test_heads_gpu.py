@@ -72,6 +72,10 @@ def test_fpn_batch_composition_is_irrelevant():
     x = O.synth_images(3, 3, 96, 72).cuda()
     full = net(x).cpu()
     assert torch.equal(full, net(x).cpu())
-    for i in range(3):     # split-K at batch 1 re-associates the fp32 sums: ~1e-7, not bit-exact
+    # The kernel a layer runs on depends on its pixel count (split-K, the small-map tiles - since round 6 conv_small.hip's two-accumulator
+    # tile from 32 tiles of 64 x 64 up): a batch-1 forward re-associates some layers' fp32 sums, which flips a 16-bit rounding here and
+    # there - the image alone and inside a batch agree to the storage format's noise, not bit for bit (bit-identity holds run to run and
+    # stream to stream at equal shapes)
+    for i in range(3):
         one = net(x[i:i + 1]).cpu()
-        assert float(1 - torch.dot(one, full[i])) < 1e-6 and float((one - full[i]).abs().max()) < 2e-4
+        assert float(1 - torch.dot(one, full[i])) < 5e-6 and float((one - full[i]).abs().max()) < 2e-4

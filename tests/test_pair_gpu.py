@@ -411,7 +411,9 @@ def test_fp16p_plumbing(monkeypatch):
     # same kernels; they agree to the fp16 noise floor of the layers behind the stem, and both sit on the oracle)
     assert (1 - O.cosine(a.numpy(), b.numpy())).max() < 5e-5 and (1 - O.cosine(a.numpy(), ref)).max() < 1e-4
     one = net(xf[1:2].cuda()).cpu()
-    assert one.shape == (2048,) and float((one - b[1]).abs().max()) < 1e-6
+    # (alone or inside a batch: the pixel count picks the kernel of a few layers - round 6: layer3.0's downsample is on conv_small.hip's
+    # tile at 3 x 30 pixels and on split-K at 30 - whose fp32 sums are associated differently; fp16 roundings flip here and there)
+    assert one.shape == (2048,) and float((one - b[1]).abs().max()) < 1e-4 and float(1 - torch.dot(one, b[1])) < 5e-6
     net.set_profiling(True)
     net(xf.cuda())
     kernels = [r['kernel'] for r in net.get_profile()]
