@@ -657,6 +657,18 @@ int conv_pick_variant(const ConvArgs& a) {
         if (t256 < 192 && t128 < 512) {
             const int v1 = find_variant("64x128_w2x2"), v2 = find_variant("64x64_w2x2_s4"), v3 = find_variant("64x64_small_s4k2");
             const bool ok2 = v2 >= 0 && conv_variant_admissible(v2, a), ok3 = v3 >= 0 && conv_variant_admissible(v3, a);
+            // Long K loops in this regime (the tuner at batch 4 of 1024^2 and ResNet-50 at 64 x 224^2, scripts/exp_tune_any.py):
+            //   * layer4's 3x3 (K = 4608) with 96-191 tiles of 128 x 128: that tile with split-K (4 096 pixels x 512 channels: 62 -> 38 us
+            //     per launch against the 64 x 128 tile, 3 136 pixels: 38 -> 33) - the small tiles stream the 4.7 MB filter once per 64 pixels;
+            //   * layer4's 2048 -> 512 conv1 (32 K-steps): the 64 x 128 tile on its four-slot ring (33 -> 21 us), not the two-slot one.
+            if (a.R * a.S > 1 && T >= 64 && t128 >= 96 && t128 < 192) {
+                const int v4 = find_variant("128x128_w2x2");
+                if (v4 >= 0 && conv_variant_admissible(v4, a)) return v4;
+            }
+            if (a.R * a.S == 1 && t64x128 >= 256 && t64x128 < 384 && T >= 32) {   // (one workgroup per CU: no second one to hide the fill)
+                const int v5 = find_variant("64x128_w2x2_s4");
+                if (v5 >= 0 && conv_variant_admissible(v5, a)) return v5;
+            }
             if (t64x128 >= 256 && v1 >= 0 && conv_variant_admissible(v1, a)) return v1;
             if (t64x128 < 192 && t64 >= 192) {
                 // (conv_small.hip's two-K-steps-per-stage tile is 8 % faster here on ONE stream - batch 1 at 1024^2 777 -> 839 img/s -

@@ -208,13 +208,17 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     # between the two regimes (batch 4 here; ResNet-50 at 64 x 224^2 has the same pixel counts): 64 x 128 tiles, two workgroups per CU
     assert pick(4, *shapes['l3.conv1']) == ('64x128_w2x2', 1) and pick(4, *shapes['l3.conv2']) == ('64x128_w2x2', 1)
     assert pick(8, *shapes['l3.conv2']) == ('128x128_w2x2', 1)
+    # long K loops in the small-map regime (round 6, from the tuner at batch 4 and ResNet-50 at 64 x 224^2: scripts/exp_tune_any.py)
+    assert pick(4, *shapes['l4.conv2']) == ('128x128_w2x2', 4) and pick(64, 7, 512, 512, 3, 1, 0) == ('128x128_w2x2', 5)
+    assert pick(4, *shapes['l4.conv1']) == ('64x128_w2x2_s4', 1) and pick(8, *shapes['l4.conv1']) == ('64x128_w2x2', 1)
+    assert pick(8, *shapes['l4.conv2']) == ('64x128_w2x2', 1) and pick(2, *shapes['l4.conv2']) == ('64x64_w2x2_s4', 1)
     # ragged maps (configs[4]'s scales at batch 16): the patch tile wastes the rest of a map's last tiles, the flattened 16-wave tile
     # does not - the picker weighs tile fill x round fill of both (round 6, from the tuner: scripts/exp_multiscale_tune.py)
     assert pick(16, 107, 256, 256, 3, 1, 0) == ('256x256_w4x4', 1) and pick(16, 38, 512, 512, 3, 1, 0) == ('256x256_w4x4', 1)
     assert pick(16, 75, 256, 256, 3, 1, 0) == ('512x128_patch3x3w', 1) and pick(16, 54, 256, 256, 3, 1, 0) == ('512x128_patch3x3w', 1)
     assert pick(16, 54, 512, 512, 3, 1, 0) == ('512x128_patch3x3w', 1) and pick(16, 150, 128, 128, 3, 1, 0) == ('512x128_patch3x3w', 1)
     # ... and a map that fills a fraction of ONE tile per image is no reason to count that tile as a workgroup (config A's layer4: 64 x 7^2)
-    assert pick(64, 7, 512, 512, 3, 1, 0) == ('64x128_w2x2_s4', 1) and pick(128, 7, 512, 512, 3, 1, 0)[0] != '512x128_patch3x3w'
+    assert pick(64, 7, 512, 512, 3, 1, 0)[0] != '512x128_patch3x3w' and pick(128, 7, 512, 512, 3, 1, 0)[0] != '512x128_patch3x3w'
     for B_ in (1, 4, 16, 64, 256):
         for H_ in (5, 7, 9, 14, 19, 27, 38):
             for C_ in (128, 256, 512):
