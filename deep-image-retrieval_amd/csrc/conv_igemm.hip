@@ -669,7 +669,10 @@ int conv_pick_variant(const ConvArgs& a) {
                 const int v5 = find_variant("64x128_w2x2_s4");
                 if (v5 >= 0 && conv_variant_admissible(v5, a)) return v5;
             }
-            if (t64x128 >= 256 && v1 >= 0 && conv_variant_admissible(v1, a)) return v1;
+            //   * 512+ output channels with 1.25+ rounds of 128 x 128 tiles (config A's layer4 1x1 convs, 392-400 tiles: 20-32 -> 17-24 us): the 64-pixel
+            //     tile streams the wider weight matrix twice as often - those keep the list's 128 x 128 tile.
+            const bool wide_n = a.Cout >= 512 && t128 >= 320;
+            if (!wide_n && t64x128 >= 256 && v1 >= 0 && conv_variant_admissible(v1, a)) return v1;
             if (t64x128 < 192 && t64 >= 192) {
                 // (conv_small.hip's two-K-steps-per-stage tile is 8 % faster here on ONE stream - batch 1 at 1024^2 777 -> 839 img/s -
                 // and, at 128 KB of LDS, 3-4 % slower on two to four: DIRTORCH_AMD_SMALL_K2 for callers that do not overlap forwards)

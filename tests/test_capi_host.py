@@ -212,6 +212,8 @@ def test_tile_heuristic_choices_for_resnet101_at_1024():
     assert pick(4, *shapes['l4.conv2']) == ('128x128_w2x2', 4) and pick(64, 7, 512, 512, 3, 1, 0) == ('128x128_w2x2', 5)
     assert pick(4, *shapes['l4.conv1']) == ('64x128_w2x2_s4', 1) and pick(8, *shapes['l4.conv1']) == ('64x128_w2x2', 1)
     assert pick(8, *shapes['l4.conv2']) == ('64x128_w2x2', 1) and pick(2, *shapes['l4.conv2']) == ('64x64_w2x2_s4', 1)
+    assert pick(64, 14, 1024, 512, 1, 1, 0) == ('128x128_w2x2', 1) and pick(64, 7, 512, 2048, 1, 1, 1) == ('128x128_w2x2', 1)   # config A's layer4: 392 / 400 tiles
+    assert pick(2, 32, 512, 2048, 1, 1, 1) == ('64x128_w2x2', 1)                                                               # 256 tiles: the 64-pixel tile stays
     # ragged maps (configs[4]'s scales at batch 16): the patch tile wastes the rest of a map's last tiles, the flattened 16-wave tile
     # does not - the picker weighs tile fill x round fill of both (round 6, from the tuner: scripts/exp_multiscale_tune.py)
     assert pick(16, 107, 256, 256, 3, 1, 0) == ('256x256_w4x4', 1) and pick(16, 38, 512, 512, 3, 1, 0) == ('256x256_w4x4', 1)
