@@ -17,14 +17,15 @@ net.compute_dtype = 'fp16p'
 net.cuda().eval()
 B = int(os.environ.get('RACE_B', 8))
 g = torch.Generator(device='cuda').manual_seed(3)
-imgs = [torch.randint(0, 256, (B, 1024, 1024, 3), generator=g, dtype=torch.uint8, device='cuda') for _ in range(3)]
+HW = tuple(int(v) for v in os.environ.get('RACE_HW', '1024x1024').split('x'))   # (round 6, late: RACE_B=1 RACE_HW=683x1024 puts conv_small.hip's tile on every layer3 conv)
+imgs = [torch.randint(0, 256, (B, HW[0], HW[1], 3), generator=g, dtype=torch.uint8, device='cuda') for _ in range(3)]
 net.set_profiling(True)
 refs = [net(x).clone() for x in imgs]
 kernels = sorted({r['kernel'] for r in net.get_profile()})
 net.set_profiling(False)
 torch.cuda.synchronize()
-print('kernel mix:', [k for k in kernels if 'patch3x3w' in k or 'patchs2' in k or 'c3c1' in k or 'wreg' in k])
-for ns in (1, 2, 3):
+print('kernel mix:', [k for k in kernels if 'patch3x3w' in k or 'patchs2' in k or 'c3c1' in k or 'wreg' in k or 'small' in k])
+for ns in ((1, 2, 4, 6) if B == 1 else (1, 2, 3)):
     pool = StreamPool(ns)
     outs = []
     for i in range(int(os.environ.get('RACE_N', 36))):
